@@ -1,0 +1,188 @@
+/*
+ * sufr_hip.h -- C ABI of libsufr_hip.so: MI355X-native suffix-array + LCP construction.
+ *
+ * Drop-in boundary for the construction path of TravisWheelerLab/sufr (v0.7.12).  The reference has
+ * no FFI of its own (it is 100 % Rust); the seam is
+ *     sufr::create                      sufr/src/lib.rs:321-371
+ *      -> SuffixArray::write(args)      libsufr/src/suffix_array.rs:460-470   (u32 / u64 width rule)
+ *      -> SufrBuilder::<T>::new(args)   libsufr/src/sufr_builder.rs:143-220
+ *           normalise text (144-160) -> sort() (495-598) -> write() (817-918)
+ * Each entry point below names the reference item it replaces.  INTEGRATION.md shows the Rust
+ * `extern "C"` binding a maintainer would add to libsufr.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success or
+ * a negative SUFR_HIP_E_* code and never throws; the message for the last failure of a context is
+ * sufr_hip_last_error(ctx).  A context is bound to one GPU and must be used from one thread at a
+ * time; the library installs no signal handlers and keeps no global state.
+ */
+#ifndef SUFR_HIP_H
+#define SUFR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUFR_HIP_ABI_VERSION 1
+
+/* .sufr serialisation version, libsufr/src/types.rs:16 */
+#define SUFR_OUTFILE_VERSION 6
+/* sentinel appended to the text by read_sequence_file, libsufr/src/types.rs:20 */
+#define SUFR_SENTINEL_CHARACTER '$'
+
+/* flags: the boolean fields of SufrBuilderArgs, libsufr/src/types.rs:527-582 */
+#define SUFR_HIP_FLAG_DNA              (1u << 0) /* is_dna */
+#define SUFR_HIP_FLAG_ALLOW_AMBIGUITY  (1u << 1) /* allow_ambiguity */
+#define SUFR_HIP_FLAG_IGNORE_SOFTMASK  (1u << 2) /* ignore_softmask (used only with RAW_TEXT) */
+#define SUFR_HIP_FLAG_RAW_TEXT         (1u << 3) /* input is not yet normalised: apply the text map
+                                                    of sufr_builder.rs:144-160 on the GPU */
+
+/* error codes */
+#define SUFR_HIP_OK              0
+#define SUFR_HIP_E_INVALID      -1  /* bad argument */
+#define SUFR_HIP_E_NO_DEVICE    -2  /* no usable HIP device: the library never falls back to CPU */
+#define SUFR_HIP_E_HIP          -3  /* HIP runtime error (message has the call) */
+#define SUFR_HIP_E_NOMEM        -4
+#define SUFR_HIP_E_CAPACITY     -5  /* output buffers too small for num_suffixes */
+#define SUFR_HIP_E_UNSUPPORTED  -6  /* valid reference option not built for the GPU yet */
+#define SUFR_HIP_E_IO           -7
+#define SUFR_HIP_E_CONFLICT     -8  /* "Cannot use max_query_len and seed_mask together" */
+#define SUFR_HIP_E_SEED_MASK    -9  /* "Invalid seed mask '<mask>'" */
+
+typedef struct sufr_hip_ctx sufr_hip_ctx;
+
+/* Phase timings and sizes of the last build (replaces the reference's log::info! phase timers,
+ * sufr_builder.rs:428,476,589).  Milliseconds are HIP-event times on the build stream. */
+typedef struct sufr_hip_stats {
+    uint64_t text_len;          /* n */
+    uint64_t num_suffixes;      /* s (this shard) */
+    uint32_t alphabet_size;     /* distinct bytes in the normalised text */
+    uint32_t bits_per_char;     /* b */
+    uint32_t chars_per_key;     /* K */
+    uint32_t digit_bits;        /* radix digit width */
+    uint32_t num_passes;        /* LSD passes of the top level */
+    uint32_t num_levels;        /* 1 + re-keying levels needed for long repeats */
+    uint64_t num_large_groups;  /* groups handed to deeper levels (all levels) */
+    uint64_t deep_records;      /* records processed by deeper levels (all levels) */
+    uint32_t top_lo, top_hi;    /* prefix-bucket range of this shard [lo, hi) */
+    uint32_t partition_workgroups; /* grid of the radix-partition kernel */
+    float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
+    float ms_normalize;         /* k_normalize_bytehist */
+    float ms_hist_text;         /* k_hist_text (+ table scan) */
+    float ms_partition;         /* k_scatter_text: THE radix-partition kernel (one launch) */
+    float ms_passes;            /* remaining LSD passes */
+    float ms_finish;            /* k_finish of the top level */
+    float ms_deep;              /* all deeper levels */
+} sufr_hip_stats;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int  sufr_hip_abi_version(void);
+/* number of HIP devices visible (0 when there is none; never initialises a context) */
+int  sufr_hip_device_count(void);
+/* replaces: rayon::ThreadPoolBuilder...build_global() (sufr/src/main.rs:32-40) as the place where
+ * execution resources are chosen.  device_id: HIP ordinal.  Returns NULL on failure; the reason is
+ * then available from sufr_hip_last_error(NULL). */
+sufr_hip_ctx *sufr_hip_create(int device_id);
+void sufr_hip_destroy(sufr_hip_ctx *ctx);
+const char *sufr_hip_last_error(const sufr_hip_ctx *ctx);
+/* optional: run the build on a caller-owned hipStream_t (e.g. torch's current stream) */
+int  sufr_hip_set_stream(sufr_hip_ctx *ctx, void *hip_stream);
+
+/* ---- text normalisation: sufr_builder.rs:144-160 (host helper; the GPU build can also do it) --- */
+int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_softmask);
+
+/* ---- the hot path: SufrBuilder::sort() + the SA/LCP stitch of write() ------------------------
+ * replaces: partition() 404-487, sort() 495-598, merge_sort()/merge() 601-767, select_pivots()
+ * 771-809 and the boundary-LCP fix 886-906 of libsufr/src/sufr_builder.rs.
+ *
+ * Device-resident variant (what bench.py times): d_text is a HIP device pointer to n text bytes,
+ * d_sa / d_lcp are device arrays with room for `cap` entries.  With num_shards > 1 the call builds
+ * only the shard_index-th prefix-bucket range (shards are balanced on the device from the k-mer
+ * histogram; concatenating shards 0..num_shards-1 gives the full arrays, and the first LCP entry of
+ * every shard but the first must be stitched with sufr_hip_lcp_pair).
+ * max_query_len / seed_mask: pass 0 / NULL; non-default values return SUFR_HIP_E_UNSUPPORTED.
+ * num_partitions and random_seed are accepted for signature parity: the result does not depend on
+ * them (pivots are replaced by on-device histogram splitters). */
+int sufr_hip_sort_device_u32(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,
+                             uint64_t max_query_len, const char *seed_mask,
+                             uint64_t num_partitions, uint64_t random_seed,
+                             uint32_t shard_index, uint32_t num_shards,
+                             void *d_sa, void *d_lcp, uint64_t cap,
+                             uint64_t *num_suffixes_out, sufr_hip_stats *stats);
+/* u64-index twin (SufrBuilder<u64>; suffix_array.rs:461 selects it when n >= u32::MAX).  Texts below
+ * 2^32-1 bytes are built with 32-bit indices on the device and widened; longer texts return
+ * SUFR_HIP_E_UNSUPPORTED for now. */
+int sufr_hip_sort_device_u64(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,
+                             uint64_t max_query_len, const char *seed_mask,
+                             uint64_t num_partitions, uint64_t random_seed,
+                             uint32_t shard_index, uint32_t num_shards,
+                             void *d_sa, void *d_lcp, uint64_t cap,
+                             uint64_t *num_suffixes_out, sufr_hip_stats *stats);
+
+/* Host-buffer variants: H2D copy of the text, build, D2H copy of SA and LCP.
+ * If norm_text_out != NULL it receives the normalised text (what write() stores in the file). */
+int sufr_hip_build_u32(sufr_hip_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t flags,
+                       uint64_t max_query_len, const char *seed_mask,
+                       uint64_t num_partitions, uint64_t random_seed,
+                       uint8_t *norm_text_out, uint32_t *sa_out, uint32_t *lcp_out, uint64_t cap,
+                       uint64_t *num_suffixes_out, sufr_hip_stats *stats);
+int sufr_hip_build_u64(sufr_hip_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t flags,
+                       uint64_t max_query_len, const char *seed_mask,
+                       uint64_t num_partitions, uint64_t random_seed,
+                       uint8_t *norm_text_out, uint64_t *sa_out, uint64_t *lcp_out, uint64_t cap,
+                       uint64_t *num_suffixes_out, sufr_hip_stats *stats);
+
+/* Exact LCP of two suffixes of a host text: the boundary fix of write(), find_lcp(prev.last,
+ * this.first, text_len, 0) (sufr_builder.rs:893-902), used to stitch shards built on different GPUs. */
+uint64_t sufr_hip_lcp_pair(const uint8_t *norm_text, uint64_t n, uint64_t a, uint64_t b);
+
+/* ---- input and output formats ------------------------------------------------------------------
+ * sufr_read_sequence_file replaces libsufr::util::read_sequence_file (util.rs:51-89): FASTA/FASTQ ->
+ * text = s1 + delimiter + s2 + ... + '$', start offsets, names (header up to first whitespace).
+ * Arrays are malloc'ed by the library; release them with sufr_sequence_data_free. */
+typedef struct sufr_sequence_data {
+    uint8_t  *seq;             /* SequenceFileData.seq */
+    uint64_t  seq_len;
+    uint64_t *start_positions; /* SequenceFileData.start_positions */
+    char    **sequence_names;  /* SequenceFileData.sequence_names */
+    uint64_t  num_sequences;
+} sufr_sequence_data;
+int  sufr_read_sequence_file(const char *path, uint8_t sequence_delimiter, sufr_sequence_data *out,
+                             char *err, size_t errlen);
+void sufr_sequence_data_free(sufr_sequence_data *d);
+
+/* sufr_write_file replaces SufrBuilder::write (sufr_builder.rs:817-918): the version-6 .sufr layout,
+ * byte for byte.  index_width is 4 or 8 (sizeof T); sequence_starts are given as u64 and stored
+ * T-wide (857).  seed_mask NULL = none; has_max_query_len 0 = None. */
+int sufr_write_file(const char *path, int is_dna, int allow_ambiguity, int ignore_softmask,
+                    const uint8_t *norm_text, uint64_t text_len, int index_width,
+                    const void *sa, const void *lcp, uint64_t num_suffixes,
+                    int has_max_query_len, uint64_t max_query_len, const char *seed_mask,
+                    const uint64_t *sequence_starts, uint64_t num_sequences,
+                    const char *const *sequence_names, char *err, size_t errlen);
+
+/* sufr_hip_create_file replaces sufr::create + SuffixArray::write (sufr/src/lib.rs:321-371,
+ * suffix_array.rs:460-470): read the sequence file, build on the GPU, write `output`.
+ * Arguments mirror CreateArgs (sufr/src/lib.rs:83-125). */
+typedef struct sufr_create_args {
+    const char *input;              /* <INPUT> */
+    const char *output;             /* -o; NULL = "<input stem>.sufr" in the CWD */
+    uint64_t    num_partitions;     /* -n, default 16 */
+    int         has_max_query_len;  /* -m given */
+    uint64_t    max_query_len;
+    int         is_dna;             /* -d */
+    int         allow_ambiguity;    /* -a */
+    int         ignore_softmask;    /* -i */
+    uint8_t     sequence_delimiter; /* -D, default '%' */
+    const char *seed_mask;          /* -s */
+    uint64_t    random_seed;        /* -r, default 42 */
+} sufr_create_args;
+int sufr_hip_create_file(sufr_hip_ctx *ctx, const sufr_create_args *args, char *path_out,
+                         size_t path_out_len, sufr_hip_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUFR_HIP_H */

@@ -1,0 +1,137 @@
+"""ctypes binding of libsufr_hip.so (include/sufr_hip.h).  No CPU fallback: if the HIP library is
+missing or no GPU is visible, every build entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "_build" / "libsufr_hip.so"
+CLI_PATH = CSRC / "_build" / "sufr"
+
+
+class SufrHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{message} (sufr_hip error {code})")
+        self.code = code
+        self.message = message
+
+
+class Stats(C.Structure):
+    """sufr_hip_stats"""
+    _fields_ = [
+        ("text_len", C.c_uint64), ("num_suffixes", C.c_uint64),
+        ("alphabet_size", C.c_uint32), ("bits_per_char", C.c_uint32), ("chars_per_key", C.c_uint32),
+        ("digit_bits", C.c_uint32), ("num_passes", C.c_uint32), ("num_levels", C.c_uint32),
+        ("num_large_groups", C.c_uint64), ("deep_records", C.c_uint64),
+        ("top_lo", C.c_uint32), ("top_hi", C.c_uint32), ("partition_workgroups", C.c_uint32),
+        ("ms_total", C.c_float), ("ms_normalize", C.c_float), ("ms_hist_text", C.c_float),
+        ("ms_partition", C.c_float), ("ms_passes", C.c_float), ("ms_finish", C.c_float),
+        ("ms_deep", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SequenceData(C.Structure):
+    _fields_ = [("seq", C.POINTER(C.c_uint8)), ("seq_len", C.c_uint64),
+                ("start_positions", C.POINTER(C.c_uint64)), ("sequence_names", C.POINTER(C.c_char_p)),
+                ("num_sequences", C.c_uint64)]
+
+
+class CreateArgs(C.Structure):
+    _fields_ = [("input", C.c_char_p), ("output", C.c_char_p), ("num_partitions", C.c_uint64),
+                ("has_max_query_len", C.c_int), ("max_query_len", C.c_uint64), ("is_dna", C.c_int),
+                ("allow_ambiguity", C.c_int), ("ignore_softmask", C.c_int), ("sequence_delimiter", C.c_uint8),
+                ("seed_mask", C.c_char_p), ("random_seed", C.c_uint64)]
+
+
+FLAG_DNA, FLAG_ALLOW_AMBIGUITY, FLAG_IGNORE_SOFTMASK, FLAG_RAW_TEXT = 1, 2, 4, 8
+
+# every symbol include/sufr_hip.h declares
+EXPORTS = [
+    "sufr_hip_abi_version", "sufr_hip_device_count", "sufr_hip_create", "sufr_hip_destroy",
+    "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
+    "sufr_hip_sort_device_u64", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
+    "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file",
+]
+
+_lib = None
+
+
+def build_extension(verbose: bool = False) -> Path:
+    """Compile the HIP library and the CLI for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", str(CSRC)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libsufr_hip.so failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SufrHipError(-2, f"{LIB_PATH} is missing: build it with sufr_amd.build_extension() "
+                               "(there is no CPU fallback)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, u32, cp = C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p
+    L.sufr_hip_abi_version.restype = C.c_int
+    L.sufr_hip_device_count.restype = C.c_int
+    L.sufr_hip_create.argtypes = [C.c_int]; L.sufr_hip_create.restype = vp
+    L.sufr_hip_destroy.argtypes = [vp]; L.sufr_hip_destroy.restype = None
+    L.sufr_hip_last_error.argtypes = [vp]; L.sufr_hip_last_error.restype = cp
+    L.sufr_hip_set_stream.argtypes = [vp, vp]; L.sufr_hip_set_stream.restype = C.c_int
+    L.sufr_hip_normalize.argtypes = [vp, vp, u64, C.c_int]; L.sufr_hip_normalize.restype = C.c_int
+    dev_sig = [vp, vp, u64, u32, u64, cp, u64, u64, u32, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(Stats)]
+    L.sufr_hip_sort_device_u32.argtypes = dev_sig; L.sufr_hip_sort_device_u32.restype = C.c_int
+    L.sufr_hip_sort_device_u64.argtypes = dev_sig; L.sufr_hip_sort_device_u64.restype = C.c_int
+    host_sig = [vp, vp, u64, u32, u64, cp, u64, u64, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(Stats)]
+    L.sufr_hip_build_u32.argtypes = host_sig; L.sufr_hip_build_u32.restype = C.c_int
+    L.sufr_hip_build_u64.argtypes = host_sig; L.sufr_hip_build_u64.restype = C.c_int
+    L.sufr_hip_lcp_pair.argtypes = [vp, u64, u64, u64]; L.sufr_hip_lcp_pair.restype = u64
+    L.sufr_read_sequence_file.argtypes = [cp, C.c_uint8, C.POINTER(SequenceData), cp, C.c_size_t]
+    L.sufr_read_sequence_file.restype = C.c_int
+    L.sufr_sequence_data_free.argtypes = [C.POINTER(SequenceData)]; L.sufr_sequence_data_free.restype = None
+    L.sufr_write_file.argtypes = [cp, C.c_int, C.c_int, C.c_int, vp, u64, C.c_int, vp, vp, u64, C.c_int, u64, cp,
+                                  vp, u64, C.POINTER(cp), cp, C.c_size_t]
+    L.sufr_write_file.restype = C.c_int
+    L.sufr_hip_create_file.argtypes = [vp, C.POINTER(CreateArgs), cp, C.c_size_t, C.POINTER(Stats)]
+    L.sufr_hip_create_file.restype = C.c_int
+    _lib = L
+    return L
+
+
+class Context:
+    """sufr_hip_ctx: one per GPU."""
+
+    def __init__(self, device: int = 0):
+        L = lib()
+        self._h = L.sufr_hip_create(device)
+        if not self._h:
+            raise SufrHipError(-2, L.sufr_hip_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sufr_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise SufrHipError(rc, lib().sufr_hip_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h

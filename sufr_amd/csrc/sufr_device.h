@@ -1,0 +1,23 @@
+// sufr_device.h -- constants and POD parameter blocks shared by the kernels and the host pipeline.
+#pragma once
+#include <stdint.h>
+
+namespace sufr {
+
+static constexpr int THREADS = 256;          // workgroup size of the radix kernels (4 wavefronts)
+static constexpr int EPT = 16;               // records / text positions per thread and tile
+static constexpr int TILE = THREADS * EPT;   // 4096
+static constexpr int HALO = 128;             // >= max K (64); text tile over-read for the rolling key
+static constexpr int TEXT_PAD = TILE + HALO + 64;  // zero bytes after the text in the workspace copy
+
+// Key layout for one build (derived from the byte histogram of the normalised text).
+struct KeyParams {
+    int b;          // bits per character code (codes 1..sigma, 0 = past end of text)
+    int K;          // characters per 64-bit key  = 64 / b
+    int dchars;     // characters per radix digit = max(1, 12 / b)
+    int dbits;      // bits per radix digit       = b * dchars  (<= 12)
+    uint32_t nbins; // 1 << dbits
+    int top_shift;  // 64 - dbits: the most significant digit (shard selector)
+};
+
+}  // namespace sufr

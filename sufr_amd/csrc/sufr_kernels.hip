@@ -1,0 +1,999 @@
+// sufr_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for suffix-array + LCP construction.
+//
+// Replaces the CPU hot loops of the reference builder (libsufr/src/sufr_builder.rs):
+//   * text normalisation            (143-160)  -> k_normalize_bytehist
+//   * eligibility + upper_bound/is_less/find_lcp bucketing (346-394, 442-462)
+//                                              -> k_hist_text / k_scatter_text (radix partition on
+//                                                 packed k-char prefix keys, LDS staged)
+//   * merge_sort / merge            (601-767)  -> k_hist_pairs / k_scatter_pairs (further LSD passes)
+//                                                 + k_finish (wave-level tie refinement, exact LCP)
+//   * boundary LCP of write()       (886-906)  -> LCP at every group boundary comes from the key xor
+//
+// Integer / byte work, HBM-bound: no MFMA.  64-wide wavefronts are hard-coded.
+//
+// Ordering contract (what the reference produces): suffixes compare as raw byte
+// strings of the normalised text; a suffix that is a proper prefix of another sorts first;
+// LCP[0] = 0, LCP[i] = exact common prefix of SA[i-1], SA[i].
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sufr_device.h"
+
+namespace sufr {
+
+static constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, WAVE);
+    hi = __shfl(hi, src, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl64_xor(uint64_t v, int m)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, WAVE);
+    hi = __shfl_xor(hi, m, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl64_up1(uint64_t v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_up(lo, 1, WAVE);
+    hi = __shfl_up(hi, 1, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// unaligned 8-byte little-endian load (the text buffer is padded with >= 64 zero bytes)
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_normalize_bytehist: reference text map (sufr_builder.rs:144-160) fused with an exact
+// 256-bin byte histogram of the NORMALISED text.  The histogram drives the alphabet -> dense code
+// table, the eligible-suffix count and the pass-count heuristic.
+// LDS histogram is replicated 32x (bin-major) so that lanes l and l+32 share a copy and every
+// lane of a half-wave hits its own bank.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n,
+                     int normalize, int ignore_softmask, unsigned long long* __restrict__ ghist)
+{
+    __shared__ uint32_t h[256 * 32];
+    for (int i = threadIdx.x; i < 256 * 32; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t copy = threadIdx.x & 31u;
+    const uint64_t nvec = n / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        uint4 w = reinterpret_cast<const uint4*>(in)[v];
+        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = ws[k], y = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t b = (x >> (8 * j)) & 0xffu;
+                if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
+                y |= b << (8 * j);
+                atomicAdd(&h[b * 32 + copy], 1u);
+            }
+            ws[k] = y;
+        }
+        reinterpret_cast<uint4*>(out)[v] = make_uint4(ws[0], ws[1], ws[2], ws[3]);
+    }
+    // tail bytes
+    if (blockIdx.x == 0) {
+        for (uint64_t i = nvec * 16 + threadIdx.x; i < n; i += 256) {
+            uint32_t b = in[i];
+            if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
+            out[i] = (uint8_t)b;
+            atomicAdd(&h[b * 32 + copy], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t sum = 0;
+        for (int c = 0; c < 32; c++) sum += h[threadIdx.x * 32 + ((c + threadIdx.x) & 31)];
+        if (sum) atomicAdd(&ghist[threadIdx.x], (unsigned long long)sum);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Key packing.  code(byte) in 1..sigma (dense rank of the byte among the bytes present in the text,
+// so integer order of codes == raw byte order); 0 = "past the end of the text" (sorts lowest,
+// sufr_builder.rs:372-379).  key = K codes of b bits, first character in the most significant bits.
+// lut[byte] = code | 0x8000 if a suffix may START with that byte (eligibility, 446-449).
+// ---------------------------------------------------------------------------------------------
+struct TileKeys {
+    uint64_t key[EPT];
+    uint32_t elig;  // bit e set: position e of this thread is a suffix start inside [0,n)
+};
+
+// Stage one text tile (TILE positions + halo) into LDS as raw bytes.
+__device__ __forceinline__ void stage_text_tile(const uint8_t* __restrict__ text, uint64_t tile0,
+                                                uint8_t* s_text)
+{
+    // text is padded: reading TILE + HALO bytes from tile0 is always in bounds.
+    const uint4* src = reinterpret_cast<const uint4*>(text + tile0);  // tile0 % 16 == 0
+    uint4* dst = reinterpret_cast<uint4*>(s_text);
+    for (int v = threadIdx.x; v < (TILE + HALO) / 16; v += THREADS) dst[v] = src[v];
+}
+
+// Each thread owns EPT consecutive positions tile0 + threadIdx.x*EPT + e and builds their keys
+// with a rolling update: key(i+1) = (key(i) << b) | code(i+K) << (64 - K*b).
+__device__ __forceinline__ void build_tile_keys(const uint8_t* s_text, const uint16_t* s_lut,
+                                                uint64_t tile0, uint64_t n, int b, int K, TileKeys& tk)
+{
+    const int p0 = threadIdx.x * EPT;
+    const int low = 64 - K * b;
+    uint64_t key = 0;
+    for (int j = 0; j < K; j++) {
+        uint64_t pos = tile0 + p0 + j;
+        uint32_t c = pos < n ? (uint32_t)(s_lut[s_text[p0 + j]] & 0x3ffu) : 0u;
+        key = (key << b) | c;
+    }
+    key <<= low;
+    tk.elig = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        uint64_t pos = tile0 + p0 + e;
+        tk.key[e] = key;
+        if (pos < n && (s_lut[s_text[p0 + e]] & 0x8000u)) tk.elig |= 1u << e;
+        uint64_t nx = pos + K;
+        uint32_t c = nx < n ? (uint32_t)(s_lut[s_text[p0 + e + K]] & 0x3ffu) : 0u;
+        key = (key << b) | ((uint64_t)c << low);
+    }
+}
+
+__device__ __forceinline__ void load_lut(const uint16_t* __restrict__ glut, uint16_t* s_lut)
+{
+    for (int i = threadIdx.x; i < 256; i += THREADS) s_lut[i] = glut[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hist_text: per-workgroup digit histogram of the first radix pass, streaming the text.
+// Row w of `table` (layout [workgroup][bin]) counts the digit `(key >> shift) & mask` of every
+// eligible position of workgroup w's text chunk whose TOP digit lies in [top_lo, top_hi)
+// (the shard filter used when a genome is split over GPUs by prefix-bucket range).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+            KeyParams kp, int shift, uint64_t chunk, uint32_t top_lo, uint32_t top_hi,
+            uint32_t* __restrict__ table)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                 // NB
+    uint8_t* s_text = smem + (size_t)kp.nbins * 4;                       // TILE + HALO
+    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_text + TILE + HALO); // 256
+
+    const uint32_t mask = kp.nbins - 1;
+    for (uint32_t i = threadIdx.x; i < kp.nbins; i += THREADS) s_cnt[i] = 0;
+    load_lut(glut, s_lut);
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t c1 = min(c0 + chunk, n);
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+        __syncthreads();
+        stage_text_tile(text, tile0, s_text);
+        __syncthreads();
+        TileKeys tk;
+        build_tile_keys(s_text, s_lut, tile0, n, kp.b, kp.K, tk);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            if (tk.elig & (1u << e)) {
+                uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift);
+                if (top >= top_lo && top < top_hi)
+                    atomicAdd(&s_cnt[(uint32_t)(tk.key[e] >> shift) & mask], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * kp.nbins;
+    for (uint32_t i = threadIdx.x; i < kp.nbins; i += THREADS) row[i] = s_cnt[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-wide exclusive scan of s_cnt[0..nbins) (nbins % THREADS == 0 or nbins < THREADS).
+// On return s_cnt holds the exclusive prefix and *s_total the total.  Also applies the per-tile
+// bookkeeping of the scatter kernels:  gdelta[d] = gbase[d] - prefix[d];  gbase[d] += count[d].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_scan_bins(uint32_t* s_cnt, uint32_t* s_gbase, uint32_t* s_gdelta,
+                                                uint32_t nbins, uint32_t* s_wsum, uint32_t* s_total)
+{
+    const uint32_t per = (nbins + THREADS - 1) / THREADS;  // bins per thread (consecutive)
+    const uint32_t d0 = threadIdx.x * per;
+    uint32_t local = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t d = d0 + k;
+        if (d < nbins) local += s_cnt[d];
+    }
+    // inclusive scan of `local` across the 256 threads: wave scan + LDS
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, WAVE);
+        if ((int)lane_id() >= o) incl += t;
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += s_wsum[w];
+    if (threadIdx.x == THREADS - 1) *s_total = wbase + incl;
+    uint32_t run = wbase + incl - local;
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t d = d0 + k;
+        if (d < nbins) {
+            uint32_t c = s_cnt[d];
+            s_cnt[d] = run;
+            uint32_t g = s_gbase[d];
+            s_gdelta[d] = g - run;
+            s_gbase[d] = g + c;
+            run += c;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter_text: THE radix-partition kernel (first pass; suffix indices are implicit).
+// Streams the text once (coalesced 16 B / lane), builds the packed key of every eligible suffix,
+// ranks the tile's elements per digit with LDS counters, stages (key, idx) in LDS in digit order and
+// writes every digit's run to its slot of the global bucket, so global stores are contiguous runs.
+// Algorithmic bytes: n (text) + 4 s (indices) [+ 8 s for the keys carried to later passes].
+// The first LSD pass has no earlier order to preserve, so ranking by LDS atomics is sufficient.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+               KeyParams kp, int shift, uint64_t chunk, uint32_t top_lo, uint32_t top_hi,
+               const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
+               uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t NB = kp.nbins;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);   // NB
+    uint32_t* s_gbase = s_cnt + NB;                        // NB
+    uint32_t* s_gdelta = s_gbase + NB;                     // NB
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NB);  // TILE
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);   // TILE
+    uint8_t* s_text = reinterpret_cast<uint8_t*>(s_idx + TILE);    // TILE + HALO
+    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_text + TILE + HALO);  // 256
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_lut + 256);   // 8
+
+    const uint32_t mask = NB - 1;
+    const uint32_t* row = table + (size_t)blockIdx.x * NB;
+    for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_gbase[i] = row[i] + binbase[i];
+    load_lut(glut, s_lut);
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t c1 = min(c0 + chunk, n);
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_cnt[i] = 0;
+        stage_text_tile(text, tile0, s_text);
+        __syncthreads();
+        TileKeys tk;
+        build_tile_keys(s_text, s_lut, tile0, n, kp.b, kp.K, tk);
+        uint32_t rank[EPT];
+        uint32_t keep = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            rank[e] = 0;
+            if (tk.elig & (1u << e)) {
+                uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift);
+                if (top >= top_lo && top < top_hi) {
+                    keep |= 1u << e;
+                    rank[e] = atomicAdd(&s_cnt[(uint32_t)(tk.key[e] >> shift) & mask], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        block_scan_bins(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 4);
+        const uint32_t total = s_misc[4];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            if (keep & (1u << e)) {
+                uint32_t d = (uint32_t)(tk.key[e] >> shift) & mask;
+                uint32_t pos = s_cnt[d] + rank[e];
+                s_key[pos] = tk.key[e];
+                s_idx[pos] = (uint32_t)(tile0 + threadIdx.x * EPT + e);
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < total; j += THREADS) {
+            uint64_t k = s_key[j];
+            uint32_t d = (uint32_t)(k >> shift) & mask;
+            uint32_t o = j + s_gdelta[d];
+            out_key[o] = k;
+            out_idx[o] = s_idx[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hist_pairs: per-workgroup digit histogram for the later LSD passes.
+// digit source: key bits (seg == nullptr) or the segment ordinal (deep levels).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_hist_pairs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ seg, uint32_t m,
+             uint32_t nbins, int shift, uint32_t chunk, uint32_t* __restrict__ table)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t mask = nbins - 1;
+    for (uint32_t i = threadIdx.x; i < nbins; i += THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    const uint32_t c0 = blockIdx.x * chunk;
+    const uint32_t c1 = min(c0 + chunk, m);
+    if (seg) {
+        for (uint32_t j = c0 + threadIdx.x; j < c1; j += THREADS)
+            atomicAdd(&s_cnt[(seg[j] >> shift) & mask], 1u);
+    } else {
+        for (uint32_t j = c0 + threadIdx.x; j < c1; j += THREADS)
+            atomicAdd(&s_cnt[(uint32_t)(keys[j] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * nbins;
+    for (uint32_t i = threadIdx.x; i < nbins; i += THREADS) row[i] = s_cnt[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level "match any": mask of the lanes whose digit equals this lane's digit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool valid)
+{
+    uint64_t m = __ballot(valid);
+    for (int k = 0; k < nbits; k++) {
+        bool bit = (d >> k) & 1u;
+        uint64_t bk = __ballot(bit);
+        m &= bit ? bk : ~bk;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter_pairs: stable LSD scatter of (key, idx [, seg]) records by one digit.
+// Tile = THREADS*EPT records, striped per wave (record = strip0 + round*64 + lane), so that rank
+// order == input order: rank = (#same digit in earlier rounds of this wave)   [per-wave LDS counter]
+//                              + (#same digit in lower lanes of this round)    [ballot match]
+//                              + (#same digit in earlier waves of the tile)    [prefix over waves]
+// Records are staged in LDS in digit order and written out as contiguous runs per digit.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_SEG>
+__global__ void __launch_bounds__(THREADS)
+k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict__ in_idx,
+                const uint32_t* __restrict__ in_seg, uint32_t m, uint32_t nbins, int nbits,
+                int shift, int digit_from_seg, uint32_t chunk,
+                const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
+                uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx,
+                uint32_t* __restrict__ out_seg)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t NB = nbins;
+    constexpr int NW = THREADS / WAVE;
+    uint32_t* s_gbase = reinterpret_cast<uint32_t*>(smem);  // NB
+    uint32_t* s_gdelta = s_gbase + NB;                      // NB
+    uint32_t* s_tot = s_gdelta + NB;                        // NB   tile count -> tile prefix
+    uint32_t* s_misc = s_tot + NB;                          // 8
+    uint8_t* s_union = reinterpret_cast<uint8_t*>(s_misc + 8);
+    // union region: per-wave counters (NW*NB u16) during ranking, then the staging arrays
+    uint16_t* s_wcnt = reinterpret_cast<uint16_t*>(s_union);
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_union);
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);
+    uint32_t* s_seg = s_idx + TILE;
+
+    const uint32_t mask = NB - 1;
+    const uint32_t* row = table + (size_t)blockIdx.x * NB;
+    for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_gbase[i] = row[i] + binbase[i];
+    const uint32_t c0 = blockIdx.x * chunk;
+    const uint32_t c1 = min(c0 + chunk, m);
+    const int wv = threadIdx.x >> 6;
+    const uint32_t ln = lane_id();
+    const uint64_t lt_mask = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
+
+    for (uint32_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+        __syncthreads();  // previous tile's copy-out done before the union region is reused
+        for (uint32_t i = threadIdx.x; i < NW * NB / 2; i += THREADS)
+            reinterpret_cast<uint32_t*>(s_wcnt)[i] = 0;
+        __syncthreads();
+        uint64_t key[EPT];
+        uint32_t idx[EPT], sg[EPT], dig[EPT], rank[EPT];
+        uint32_t valid = 0;
+        const uint32_t strip0 = tile0 + wv * (EPT * WAVE);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            uint32_t j = strip0 + e * WAVE + ln;
+            if (j < c1) {
+                valid |= 1u << e;
+                key[e] = in_key[j];
+                idx[e] = in_idx[j];
+                sg[e] = HAS_SEG ? in_seg[j] : 0u;
+            } else {
+                key[e] = 0; idx[e] = 0; sg[e] = 0;
+            }
+        }
+        volatile uint16_t* my = s_wcnt + (size_t)wv * NB;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            bool v = valid & (1u << e);
+            uint32_t d = (digit_from_seg ? (sg[e] >> shift) : (uint32_t)(key[e] >> shift)) & mask;
+            dig[e] = d;
+            uint64_t mm = match_digit(d, nbits, v);
+            uint32_t before = 0;
+            if (v) {
+                before = my[d];
+                uint32_t lower = __popcll(mm & lt_mask);
+                rank[e] = before + lower;
+                if (lower == 0) my[d] = (uint16_t)(before + __popcll(mm));
+            } else {
+                rank[e] = 0;
+            }
+        }
+        __syncthreads();
+        // per digit: exclusive prefix over waves (in place) and tile count
+        for (uint32_t d = threadIdx.x; d < NB; d += THREADS) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                uint32_t c = s_wcnt[(size_t)w * NB + d];
+                s_wcnt[(size_t)w * NB + d] = (uint16_t)run;
+                run += c;
+            }
+            s_tot[d] = run;
+        }
+        __syncthreads();
+        block_scan_bins(s_tot, s_gbase, s_gdelta, NB, s_misc, s_misc + 4);
+        const uint32_t total = s_misc[4];
+        // final tile-local position of every record (registers), before the union region is reused
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (valid & (1u << e)) rank[e] += s_tot[dig[e]] + my[dig[e]];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            if (valid & (1u << e)) {
+                s_key[rank[e]] = key[e];
+                s_idx[rank[e]] = idx[e];
+                if (HAS_SEG) s_seg[rank[e]] = sg[e];
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < total; j += THREADS) {
+            uint64_t k = s_key[j];
+            uint32_t sgv = HAS_SEG ? s_seg[j] : 0u;
+            uint32_t d = (digit_from_seg ? (sgv >> shift) : (uint32_t)(k >> shift)) & mask;
+            uint32_t o = j + s_gdelta[d];
+            out_key[o] = k;
+            out_idx[o] = s_idx[j];
+            if (HAS_SEG) out_seg[o] = sgv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scan of the [workgroup][bin] histogram table.
+//   k_scan_table_cols: per bin, exclusive prefix over workgroups (in place) + bin totals.
+//   k_scan_bins:       exclusive prefix over the bin totals (single workgroup) + grand total.
+// A record of workgroup w with digit d goes to  binbase[d] + table[w][d] + (rank inside w).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_scan_table_cols(uint32_t* __restrict__ table, uint32_t nwg, uint32_t nbins,
+                  uint32_t* __restrict__ bintot)
+{
+    uint32_t d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= nbins) return;
+    uint32_t run = 0;
+    uint32_t w = 0;
+    for (; w + 8 <= nwg; w += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = table[(size_t)(w + k) * nbins + d];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            table[(size_t)(w + k) * nbins + d] = run;
+            run += c[k];
+        }
+    }
+    for (; w < nwg; w++) {
+        uint32_t c = table[(size_t)w * nbins + d];
+        table[(size_t)w * nbins + d] = run;
+        run += c;
+    }
+    bintot[d] = run;
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_bins(const uint32_t* __restrict__ bintot, uint32_t nbins, uint32_t* __restrict__ binbase,
+            unsigned long long* __restrict__ total_out)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t per = (nbins + 255) / 256;
+    const uint32_t d0 = threadIdx.x * per;
+    uint32_t local = 0;
+    for (uint32_t k = 0; k < per; k++)
+        if (d0 + k < nbins) local += bintot[d0 + k];
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, WAVE);
+        if ((int)lane_id() >= o) incl += t;
+    }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += s_w[w];
+    uint32_t run = wbase + incl - local;
+    for (uint32_t k = 0; k < per; k++) {
+        if (d0 + k < nbins) {
+            binbase[d0 + k] = run;
+            run += bintot[d0 + k];
+        }
+    }
+    if (threadIdx.x == 255 && total_out) *total_out = (unsigned long long)run;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finish: wave-level finisher.  Input: records sorted by (segment, top C characters of the key).
+// A *group* is a maximal run of records equal in (segment, top C chars).  Wave t owns the groups
+// whose first record lies in slots [64t, 64t+64) and sees the 128-slot window [64t, 64t+128).
+//   * groups that end inside the window ("small") are completely ordered here:
+//       round 0 sorts by the whole K-character key; rounds r >= 1 fetch the next 8 raw text bytes of
+//       every still-tied suffix and sort by them (128-element bitonic network over 64 lanes x 2
+//       registers, __shfl-based), splitting tie groups until every suffix is alone;
+//     the LCP of a split is  depth + (common leading chars of the two keys / words)  -- exact.
+//   * groups that run past the window ("large") are appended to `large_heads` and re-keyed at depth
+//     + C by the next level (k_gather_keys ... k_finish again).
+// The LCP at a group's first record is the key-xor LCP with the record before it (another group),
+// i.e. the boundary LCP the reference recomputes in write() (sufr_builder.rs:893-902).
+// ---------------------------------------------------------------------------------------------
+struct Rec {
+    uint64_t k;     // sort word (key, or 8 text bytes big-endian)
+    uint32_t idx;   // suffix position
+    uint32_t gv;    // (group id << 8) | valid-byte count   -- primary / tertiary sort fields
+};
+
+__device__ __forceinline__ bool rec_less(const Rec& a, const Rec& b)
+{
+    uint32_t ga = a.gv >> 8, gb = b.gv >> 8;
+    if (ga != gb) return ga < gb;
+    if (a.k != b.k) return a.k < b.k;
+    return (a.gv & 0xffu) < (b.gv & 0xffu);
+}
+
+__device__ __forceinline__ void cmpx_lane(Rec& r, int j, bool keep_min)
+{
+    Rec o;
+    o.k = shfl64_xor(r.k, j);
+    o.idx = __shfl_xor(r.idx, j, WAVE);
+    o.gv = __shfl_xor(r.gv, j, WAVE);
+    bool o_less = rec_less(o, r);
+    bool r_less = rec_less(r, o);
+    bool take = keep_min ? o_less : r_less;
+    if (take) r = o;
+}
+
+// sort the 128 records (slot = lane for r0, 64 + lane for r1) ascending
+__device__ __forceinline__ void bitonic128(Rec& r0, Rec& r1)
+{
+    const uint32_t ln = lane_id();
+    for (int k = 2; k <= 128; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {
+                // partner is the other register of the same lane; k == 128 -> ascending
+                if (rec_less(r1, r0)) { Rec t = r0; r0 = r1; r1 = t; }
+            } else {
+                bool up0 = (k == 128) ? true : ((ln & k) == 0);
+                bool up1 = (k == 128) ? true : (((ln + 64) & k) == 0);
+                bool lower = (ln & j) == 0;
+                cmpx_lane(r0, j, lower == up0);
+                cmpx_lane(r1, j, lower == up1);
+            }
+        }
+    }
+}
+
+// inclusive max-scan over the 128 slots of (v0 @ slot lane, v1 @ slot 64+lane)
+__device__ __forceinline__ void maxscan128(int& v0, int& v1)
+{
+    const int ln = (int)lane_id();
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t0 = __shfl_up(v0, o, WAVE);
+        int t1 = __shfl_up(v1, o, WAVE);
+        if (ln >= o) { v0 = max(v0, t0); v1 = max(v1, t1); }
+    }
+    int last0 = __shfl(v0, 63, WAVE);
+    v1 = max(v1, last0);
+}
+
+// suffix-min scan: for each slot, the smallest value at a slot strictly greater than it
+__device__ __forceinline__ void next_min128(int h0, int h1, int sentinel, int& n0, int& n1)
+{
+    const int ln = (int)lane_id();
+    // inclusive suffix-min
+    int s0 = h0, s1 = h1;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t0 = __shfl_down(s0, o, WAVE);
+        int t1 = __shfl_down(s1, o, WAVE);
+        if (ln + o < WAVE) { s0 = min(s0, t0); s1 = min(s1, t1); }
+    }
+    int first1 = __shfl(s1, 0, WAVE);
+    s0 = min(s0, first1);
+    // exclusive: shift by one slot
+    int e0 = __shfl_down(s0, 1, WAVE);
+    int e1 = __shfl_down(s1, 1, WAVE);
+    if (ln == 63) { e0 = first1; e1 = sentinel; }
+    n0 = min(e0, sentinel); n1 = min(e1, sentinel);
+}
+
+template <bool DEEP>
+__global__ void __launch_bounds__(256)
+k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
+         const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos, uint32_t m,
+         const uint8_t* __restrict__ text, uint64_t n, uint64_t depth, KeyParams kp, int group_shift,
+         uint32_t* __restrict__ SA, uint32_t* __restrict__ LCP,
+         uint32_t* __restrict__ large_heads, uint32_t* __restrict__ large_count)
+{
+    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t base = wave * 64;
+    if (base >= m) return;
+    const int ln = (int)lane_id();
+    const uint32_t j0 = base + ln, j1 = base + 64 + ln;
+    const bool in0 = j0 < m, in1 = j1 < m;
+
+    Rec r0, r1;
+    r0.k = in0 ? keys[j0] : ~0ull;  r0.idx = in0 ? idxs[j0] : 0u;
+    r1.k = in1 ? keys[j1] : ~0ull;  r1.idx = in1 ? idxs[j1] : 0u;
+    uint32_t sg0 = 0, sg1 = 0;
+    if (DEEP) { sg0 = in0 ? segs[j0] : 0xffffffffu; sg1 = in1 ? segs[j1] : 0xffffffffu; }
+
+    // record before the window (slot -1) and after it (slot 128)
+    uint64_t kprev = 0, knext = 0; uint32_t sprev = 0, snext = 0;
+    const bool has_prev = base > 0;
+    const bool has_next = (base + 128) < m;
+    if (has_prev) { kprev = keys[base - 1]; if (DEEP) sprev = segs[base - 1]; }
+    if (has_next) { knext = keys[base + 128]; if (DEEP) snext = segs[base + 128]; }
+
+    // ---- head flags (group = equal segment and equal top-C characters) ----------------------
+    uint64_t p0 = shfl64_up1(r0.k), p1 = shfl64_up1(r1.k);
+    uint32_t ps0 = __shfl_up(sg0, 1, WAVE), ps1 = __shfl_up(sg1, 1, WAVE);
+    uint64_t last0k = shfl64(r0.k, 63); uint32_t last0s = __shfl(sg0, 63, WAVE);
+    if (ln == 0) { p0 = kprev; ps0 = sprev; p1 = last0k; ps1 = last0s; }
+    bool segdiff0 = DEEP && (ps0 != sg0), segdiff1 = DEEP && (ps1 != sg1);
+    bool h0 = !in0 || (ln == 0 && !has_prev) || segdiff0 || ((p0 >> group_shift) != (r0.k >> group_shift));
+    bool h1 = !in1 || segdiff1 || ((p1 >> group_shift) != (r1.k >> group_shift));
+    // is slot 128 a head?  (needed to know whether a group ends exactly at the window end)
+    uint64_t last1k = shfl64(r1.k, 63); uint32_t last1s = __shfl(sg1, 63, WAVE);
+    bool h128 = !has_next || (DEEP && snext != last1s) || ((knext >> group_shift) != (last1k >> group_shift));
+
+    // boundary LCP of a head with the record before it (different group => differs inside the key)
+    // and first-of-segment flags (their LCP belongs to the parent level)
+    uint32_t blcp0 = 0, blcp1 = 0;
+    {
+        uint64_t x0 = p0 ^ r0.k, x1 = p1 ^ r1.k;
+        blcp0 = x0 ? (uint32_t)(__clzll(x0) / kp.b) : (uint32_t)kp.K;
+        blcp1 = x1 ? (uint32_t)(__clzll(x1) / kp.b) : (uint32_t)kp.K;
+    }
+    const bool first0 = (ln == 0 && !has_prev) || segdiff0;   // no LCP to emit from this level
+    const bool first1 = segdiff1;
+
+    // ---- group ids: head slot of the group each slot belongs to ------------------------------
+    int g0 = h0 ? ln : -1, g1 = h1 ? (64 + ln) : -1;
+    maxscan128(g0, g1);
+    int hh0 = h0 ? ln : 1000, hh1 = h1 ? (64 + ln) : 1000;
+    int nx0, nx1;
+    next_min128(hh0, hh1, h128 ? 128 : 1000, nx0, nx1);   // next head slot after each slot
+    // group end for each slot = next head after the slot's own position scanning forward;
+    // for a slot inside a group that is the first head found after it.
+    const bool own0 = in0 && g0 >= 0 && g0 < 64, own1 = in1 && g1 >= 0 && g1 < 64;
+    // end of the group that slot belongs to: next head after this slot, propagated: every member
+    // sees the same "next head after me" only if no head lies between -- true by definition.
+    const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
+    // large groups: reported once, by their head slot
+    if (own0 && h0 && !small0) {
+        uint32_t at = atomicAdd(large_count, 1u);
+        large_heads[at] = j0;
+        if (!first0) LCP[DEEP ? opos[j0] : j0] = (uint32_t)depth + blcp0;
+        else if (!DEEP) LCP[j0] = 0;
+    }
+    // (a head can never sit in r1 and be owned: owned heads are slots < 64)
+
+    // group size > 1 ?
+    const bool multi0 = small0 && !(h0 && nx0 == ln + 1);
+    const bool multi1 = small1 && !(h1 && nx1 == 64 + ln + 1);
+    // sort group id: members of a small multi-record group share their head slot, everything
+    // else is pinned to its own slot.
+    uint32_t sgid0 = multi0 ? (uint32_t)g0 : (uint32_t)ln;
+    uint32_t sgid1 = multi1 ? (uint32_t)g1 : (uint32_t)(64 + ln);
+    uint32_t lcp0 = (uint32_t)depth + blcp0, lcp1 = (uint32_t)depth + blcp1;  // valid at heads
+
+    bool act0 = multi0, act1 = multi1;
+    if (__ballot(act0 || act1)) {
+        // ---- round 0: order by the full K-character key ------------------------------------
+        r0.gv = (sgid0 << 8) | 8u; r1.gv = (sgid1 << 8) | 8u;
+        bitonic128(r0, r1);
+        uint64_t d = depth + (uint64_t)kp.K;     // chars known equal inside a tie group
+        int round = 0;
+        // distinct suffixes must separate within n bytes; the bound only guards against a hang
+        const uint64_t max_round = n / 8 + 8;
+        for (;;) {
+            if ((uint64_t)round > max_round) break;
+            // split tie groups: slot j starts a new group if it differs from slot j-1
+            Rec q0, q1;
+            q0.k = shfl64_up1(r0.k); q0.gv = __shfl_up(r0.gv, 1, WAVE);
+            q1.k = shfl64_up1(r1.k); q1.gv = __shfl_up(r1.gv, 1, WAVE);
+            uint64_t l0k = shfl64(r0.k, 63); uint32_t l0g = __shfl(r0.gv, 63, WAVE);
+            if (ln == 0) { q0.k = 0; q0.gv = 0xffffffffu; q1.k = l0k; q1.gv = l0g; }
+            bool same0 = act0 && ((q0.gv >> 8) == (r0.gv >> 8));
+            bool same1 = act1 && ((q1.gv >> 8) == (r1.gv >> 8));
+            // tie <=> same group, equal word, both fully valid
+            bool tie0 = same0 && q0.k == r0.k && (q0.gv & 0xffu) == 8u && (r0.gv & 0xffu) == 8u;
+            bool tie1 = same1 && q1.k == r1.k && (q1.gv & 0xffu) == 8u && (r1.gv & 0xffu) == 8u;
+            if (same0 && !tie0) {
+                uint64_t x = q0.k ^ r0.k;
+                uint32_t common = round == 0 ? (x ? (uint32_t)(__clzll(x) / kp.b) : (uint32_t)kp.K)
+                                             : (x ? (uint32_t)(__clzll(x) >> 3) : 8u);
+                uint32_t va = q0.gv & 0xffu, vb = r0.gv & 0xffu;
+                if (round > 0) common = min(common, min(va, vb));
+                lcp0 = (uint32_t)(round == 0 ? depth : d) + common;
+            }
+            if (same1 && !tie1) {
+                uint64_t x = q1.k ^ r1.k;
+                uint32_t common = round == 0 ? (x ? (uint32_t)(__clzll(x) / kp.b) : (uint32_t)kp.K)
+                                             : (x ? (uint32_t)(__clzll(x) >> 3) : 8u);
+                uint32_t va = q1.gv & 0xffu, vb = r1.gv & 0xffu;
+                if (round > 0) common = min(common, min(va, vb));
+                lcp1 = (uint32_t)(round == 0 ? depth : d) + common;
+            }
+            // new group ids: head = start of a tie run
+            int ng0 = (act0 && tie0) ? -1 : ln, ng1 = (act1 && tie1) ? -1 : (64 + ln);
+            maxscan128(ng0, ng1);
+            // a slot stays active iff its tie run has more than one member
+            bool nt0 = tie0, nt1 = tie1;                   // I tie with my predecessor
+            bool s0n = __shfl_down((int)nt0, 1, WAVE);      // my successor ties with me
+            bool s1n = __shfl_down((int)nt1, 1, WAVE);
+            bool f1 = __shfl((int)nt1, 0, WAVE);
+            if (ln == 63) { s0n = f1; s1n = false; }
+            act0 = act0 && (nt0 || s0n);
+            act1 = act1 && (nt1 || s1n);
+            sgid0 = act0 ? (uint32_t)ng0 : (uint32_t)ln;
+            sgid1 = act1 ? (uint32_t)ng1 : (uint32_t)(64 + ln);
+            if (!__ballot(act0 || act1)) break;
+            // ---- next round: fetch 8 raw text bytes at depth d for the tied suffixes ---------
+            if (round > 0) d += 8;
+            round++;
+            uint32_t v0 = 8, v1 = 8;
+            uint64_t w0 = 0, w1 = 0;
+            if (act0) {
+                uint64_t p = (uint64_t)r0.idx + d;
+                v0 = p >= n ? 0u : (uint32_t)min((uint64_t)8, n - p);
+                w0 = v0 ? __builtin_bswap64(load_u64_unaligned(text + p)) : 0ull;
+                if (v0 < 8) w0 &= v0 ? (~0ull << (8 * (8 - v0))) : 0ull;
+            }
+            if (act1) {
+                uint64_t p = (uint64_t)r1.idx + d;
+                v1 = p >= n ? 0u : (uint32_t)min((uint64_t)8, n - p);
+                w1 = v1 ? __builtin_bswap64(load_u64_unaligned(text + p)) : 0ull;
+                if (v1 < 8) w1 &= v1 ? (~0ull << (8 * (8 - v1))) : 0ull;
+            }
+            r0.k = w0; r0.gv = (sgid0 << 8) | v0;
+            r1.k = w1; r1.gv = (sgid1 << 8) | v1;
+            // skip the sort when every tie group read identical full words (deep repeats)
+            uint64_t hk0 = shfl64_up1(r0.k), hk1 = shfl64_up1(r1.k);
+            uint32_t hg0 = __shfl_up(r0.gv, 1, WAVE), hg1 = __shfl_up(r1.gv, 1, WAVE);
+            uint64_t e0k = shfl64(r0.k, 63); uint32_t e0g = __shfl(r0.gv, 63, WAVE);
+            if (ln == 0) { hk0 = r0.k; hg0 = r0.gv; hk1 = e0k; hg1 = e0g; }
+            bool diff0 = act0 && (hg0 >> 8) == (r0.gv >> 8) && (hk0 != r0.k || (hg0 & 0xffu) != (r0.gv & 0xffu));
+            bool diff1 = act1 && (hg1 >> 8) == (r1.gv >> 8) && (hk1 != r1.k || (hg1 & 0xffu) != (r1.gv & 0xffu));
+            if (__ballot(diff0 || diff1)) bitonic128(r0, r1);
+        }
+    }
+    // ---- write the owned, completely ordered slots ----------------------------------------------
+    if (small0) {
+        uint32_t o = DEEP ? opos[j0] : j0;
+        SA[o] = r0.idx;
+        if (!(first0 && h0)) LCP[o] = lcp0;
+        else if (!DEEP) LCP[o] = 0;
+    }
+    if (small1) {
+        uint32_t o = DEEP ? opos[j1] : j1;
+        SA[o] = r1.idx;
+        if (!(first1 && h1)) LCP[o] = lcp1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deep levels: large groups are re-keyed at depth + C.
+// ---------------------------------------------------------------------------------------------
+// keys[e] = packed K-character key of suffix idx[e] starting `depth` characters in.
+__global__ void __launch_bounds__(256)
+k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+              const uint32_t* __restrict__ idx, uint32_t m, uint64_t depth, KeyParams kp,
+              uint64_t* __restrict__ keys)
+{
+    __shared__ uint16_t s_lut[256];
+    for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
+    __syncthreads();
+    uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    uint64_t p = (uint64_t)idx[e] + depth;
+    uint64_t key = 0;
+    int j = 0;
+    while (j < kp.K) {
+        uint64_t w = (p + j < n) ? load_u64_unaligned(text + p + j) : 0ull;
+        int lim = min(8, kp.K - j);
+        for (int t = 0; t < lim; t++) {
+            uint32_t c = (p + j + t < n) ? (uint32_t)(s_lut[(w >> (8 * t)) & 0xffu] & 0x3ffu) : 0u;
+            key = (key << kp.b) | c;
+        }
+        j += lim;
+    }
+    keys[e] = key << (64 - kp.K * kp.b);
+}
+
+// size of every large group: upper bound of (segment, top-C chars) in the sorted records
+template <bool DEEP>
+__global__ void __launch_bounds__(256)
+k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ segs, uint32_t m,
+               int group_shift, const uint32_t* __restrict__ heads, uint32_t L,
+               uint32_t* __restrict__ sizes, uint32_t* __restrict__ maxsize)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= L) return;
+    uint32_t h = heads[k];
+    uint64_t top = keys[h] >> group_shift;
+    uint32_t sg = DEEP ? segs[h] : 0u;
+    uint32_t lo = h + 1, hi = m;    // first position > h that is not in the group
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        bool in_group = (!DEEP || segs[mid] == sg) && ((keys[mid] >> group_shift) == top);
+        // records are sorted by (seg, top): everything in (h, end) is in the group
+        if (in_group) lo = mid + 1; else hi = mid;
+    }
+    uint32_t sz = lo - h;
+    sizes[k] = sz;
+    atomicMax(maxsize, sz);
+}
+
+// new level: slot t of the new active array takes the record src = heads[k] + (t - start[k])
+template <bool DEEP>
+__global__ void __launch_bounds__(256)
+k_build_level(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ opos,
+              const uint32_t* __restrict__ heads, const uint32_t* __restrict__ start, uint32_t L,
+              uint32_t m_new, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
+              uint32_t* __restrict__ opos_new)
+{
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= m_new) return;
+    uint32_t lo = 0, hi = L;   // last k with start[k] <= t
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (start[mid] <= t) lo = mid; else hi = mid;
+    }
+    uint32_t src = heads[lo] + (t - start[lo]);
+    idx_new[t] = idx[src];
+    seg_new[t] = lo;
+    opos_new[t] = DEEP ? opos[src] : src;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic exclusive scan of u32 (3 kernels): used for the large-group start offsets
+// ---------------------------------------------------------------------------------------------
+static constexpr int SCAN_ITEMS = 2048;  // per workgroup
+
+__global__ void __launch_bounds__(256)
+k_scan_reduce(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s[4];
+    uint32_t b0 = blockIdx.x * SCAN_ITEMS;
+    uint32_t sum = 0;
+    for (uint32_t i = b0 + threadIdx.x; i < min(b0 + SCAN_ITEMS, count); i += 256) sum += in[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, WAVE);
+    if (lane_id() == 0) s[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_partials(uint32_t* __restrict__ partial, uint32_t nblocks, unsigned long long* __restrict__ total)
+{
+    // single workgroup, sequential chunks of 256
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+        uint32_t i = b0 + threadIdx.x;
+        uint32_t v = i < nblocks ? partial[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            uint32_t t = __shfl_up(incl, o, WAVE);
+            if ((int)lane_id() >= o) incl += t;
+        }
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += s_w[w];
+        uint32_t carry = s_carry;
+        if (i < nblocks) partial[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = (unsigned long long)s_carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_apply(const uint32_t* __restrict__ in, uint32_t count, const uint32_t* __restrict__ partial,
+             uint32_t* __restrict__ out)
+{
+    // one workgroup scans its SCAN_ITEMS sequentially in chunks of 256
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    uint32_t b0 = blockIdx.x * SCAN_ITEMS;
+    if (threadIdx.x == 0) s_carry = partial[blockIdx.x];
+    __syncthreads();
+    for (uint32_t c = 0; c < SCAN_ITEMS; c += 256) {
+        uint32_t i = b0 + c + threadIdx.x;
+        uint32_t v = i < count ? in[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            uint32_t t = __shfl_up(incl, o, WAVE);
+            if ((int)lane_id() >= o) incl += t;
+        }
+        if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wbase += s_w[w];
+        uint32_t carry = s_carry;
+        if (i < count) out[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + wbase + incl;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// debug / verification kernel: first index where records are not sorted by (seg, key >> shift)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_check_sorted(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ segs, uint32_t m,
+               int shift, uint32_t* __restrict__ first_bad)
+{
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0 || j >= m) return;
+    bool bad;
+    if (segs) {
+        bad = segs[j - 1] > segs[j] || (segs[j - 1] == segs[j] && (keys[j - 1] >> shift) > (keys[j] >> shift));
+    } else {
+        bad = (keys[j - 1] >> shift) > (keys[j] >> shift);
+    }
+    if (bad) atomicMin(first_bad, j);
+}
+
+// widen u32 results for the u64-index ABI (texts below 2^32-1 only)
+__global__ void __launch_bounds__(256)
+k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = in[i];
+}
+
+}  // namespace sufr
+
+#include "sufr_launch.inc"
+#include "sufr_capi.inc"

@@ -1,0 +1,226 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against
+  * the reference's golden .sufr files (whole-file byte equality),
+  * the CPU oracle on the same seeded inputs (bit-exact SA and LCP),
+  * size-independent properties at larger sizes (permutation of the eligible positions, sortedness,
+    exact LCP on sampled adjacent ranks)."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import sufr_amd
+from sufr_amd import synth
+from oracle_helper import GOLDEN, GOLDEN_CASES, check_sa_lcp_properties, naive_sa_lcp, parse_sufr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sufr_amd.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_build(ctx, raw: np.ndarray, *, is_dna=True, allow_ambiguity=False, ignore_softmask=False, width=4):
+    """sufr_hip_build_u32/u64 on a raw (un-normalised) host text."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    args = sufr_amd.SufrBuilderArgs(text=raw, is_dna=is_dna, allow_ambiguity=allow_ambiguity,
+                                    ignore_softmask=ignore_softmask)
+    b = sufr_amd.SufrBuilder(args, index_width=width, ctx=ctx, write=False)
+    return b
+
+
+def assert_matches_oracle(ctx, oracle, raw, *, is_dna=True, allow_ambiguity=False, ignore_softmask=False,
+                          threads=8):
+    b = gpu_build(ctx, raw, is_dna=is_dna, allow_ambiguity=allow_ambiguity, ignore_softmask=ignore_softmask)
+    norm = oracle.normalize(np.ascontiguousarray(raw, dtype=np.uint8), ignore_softmask)
+    assert np.array_equal(b.text, norm), "normalised text differs"
+    if norm.size >= 4:
+        sa, lcp, st = oracle.build(norm, is_dna=is_dna, allow_ambiguity=allow_ambiguity, threads=threads)
+    else:  # the reference cannot build texts shorter than 4 (text_len/4 == 0 partitions): naive witness
+        sa, lcp = naive_sa_lcp(norm, is_dna, allow_ambiguity)
+    assert b.num_suffixes == sa.size
+    bad = np.nonzero(b.suffix_array != sa)[0]
+    assert bad.size == 0, f"SA differs at rank {bad[0]} of {sa.size}: got {b.suffix_array[bad[0]]} want {sa[bad[0]]}"
+    bad = np.nonzero(b.lcp != lcp)[0]
+    assert bad.size == 0, f"LCP differs at rank {bad[0]} of {sa.size}: got {b.lcp[bad[0]]} want {lcp[bad[0]]}"
+    return b
+
+
+# ---- the reference's golden files -----------------------------------------------------------------
+GPU_GOLDEN = sorted(n for n in GOLDEN_CASES if "masked" not in n)
+
+
+@pytest.mark.parametrize("name", GPU_GOLDEN)
+def test_golden_file_bytes(tmp_path, name):
+    case = dict(GOLDEN_CASES[name])
+    fa = GOLDEN / "inputs" / case.pop("fa")
+    out = tmp_path / name
+    delim = case.pop("delimiter", b"%").decode()
+    path, st = sufr_amd.create(str(fa), str(out), sequence_delimiter=delim, **case)
+    assert path == str(out)
+    assert out.read_bytes() == (GOLDEN / "expected" / name).read_bytes()
+
+
+def test_native_cli_binary_golden(tmp_path):
+    """`sufr create --dna -n 2 data/inputs/2.fa` (BASELINE config C1) through the native binary."""
+    out = tmp_path / "2.sufr"
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "--log", "info", "create", "--dna", "-n", "2", "-o", str(out),
+                        str(GOLDEN / "inputs" / "2.fa")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Wrote 260 bytes" in r.stdout
+    assert out.read_bytes() == (GOLDEN / "expected" / "2.sufr").read_bytes()
+    # default output name: <input stem>.sufr in the CWD (sufr/src/lib.rs:334-340)
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "cr", "-d", str(GOLDEN / "inputs" / "1.fa")], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and (tmp_path / "1.sufr").read_bytes() == (GOLDEN / "expected" / "1.sufr").read_bytes()
+
+
+def test_lib_rs_inline_vectors(ctx):  # libsufr/src/lib.rs:45-140
+    d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "2.fa", b"N")
+    b = gpu_build(ctx, np.frombuffer(d.seq, dtype=np.uint8))
+    assert b.text.tobytes() == b"ACGTACGTNACGTACGT$"
+    assert b.suffix_array.tolist() == [17, 13, 9, 0, 4, 14, 10, 1, 5, 15, 11, 2, 6, 16, 12, 3, 7]
+    assert b.lcp.tolist() == [0, 0, 4, 8, 4, 0, 3, 7, 3, 0, 2, 6, 2, 0, 1, 5, 1]
+    d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "1.fa", b"N")
+    b = gpu_build(ctx, np.frombuffer(d.seq, dtype=np.uint8), allow_ambiguity=True, width=8)   # SufrBuilder<u64>
+    assert b.suffix_array.dtype == np.uint64
+    assert b.suffix_array.tolist() == [10, 6, 0, 7, 1, 8, 2, 5, 4, 9, 3]
+    assert b.lcp.tolist() == [0, 0, 4, 0, 3, 0, 2, 0, 1, 0, 1]
+    d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "smol.fa", b"N")
+    b = gpu_build(ctx, np.frombuffer(d.seq, dtype=np.uint8))
+    assert b.num_suffixes == 364
+
+
+def test_unsupported_options_fail_loudly(ctx, tmp_path):
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        sufr_amd.create(str(GOLDEN / "inputs" / "uniprot.fa"), str(tmp_path / "m.sufr"), seed_mask="10111011")
+    assert e.value.code == -6
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        sufr_amd.create(str(GOLDEN / "inputs" / "uniprot.fa"), str(tmp_path / "m.sufr"), seed_mask="0110")
+    assert e.value.code == -9 and "Invalid seed mask '0110'" in str(e.value)
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        sufr_amd.create(str(GOLDEN / "inputs" / "1.fa"), str(tmp_path / "m.sufr"), max_query_len=3, is_dna=True)
+    assert e.value.code == -6
+
+
+# ---- seeded inputs against the oracle -----------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 17, 63, 64, 65, 127, 128, 129, 255, 4095, 4096, 4097, 8191, 8193,
+                               65_536, 300_000])
+def test_random_dna_sizes(ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n - 1)] if n > 1 else np.empty(0, np.uint8)
+    raw = np.concatenate([body, np.frombuffer(b"$", dtype=np.uint8)])
+    assert_matches_oracle(ctx, oracle, raw)
+
+
+def test_empty_text(ctx):
+    b = gpu_build(ctx, np.empty(0, dtype=np.uint8))
+    assert b.num_suffixes == 0
+
+
+@pytest.mark.parametrize("soft", [False, True])
+@pytest.mark.parametrize("amb", [False, True])
+def test_softmask_ambiguity_delimiters(ctx, oracle, soft, amb):
+    x, starts = synth.syn_human(400_000, seed=11)
+    assert_matches_oracle(ctx, oracle, x.numpy(), ignore_softmask=soft, allow_ambiguity=amb)
+
+
+def test_only_ineligible(ctx, oracle):
+    raw = np.frombuffer(b"NNNNNNNNNNNNNNNNNNNNNNNN%NNNNNNNN", dtype=np.uint8)
+    b = gpu_build(ctx, raw)
+    assert b.num_suffixes == 0
+
+
+@pytest.mark.parametrize("kind", ["all_a", "acgt_k", "fib", "two_identical", "n_run", "tandem"])
+@pytest.mark.parametrize("n", [100, 5000])
+def test_adversarial_micro_inputs(ctx, oracle, kind, n):
+    assert_matches_oracle(ctx, oracle, synth.adversarial(kind, n, seed=n))
+
+
+def test_long_repeats_need_deeper_levels(ctx, oracle):
+    """Planted long exact repeats and tandem arrays: groups larger than a wave window, LCP >> key."""
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    body = acgt[rng.integers(0, 4, size=200_000)]
+    unit = acgt[rng.integers(0, 4, size=3000)]
+    for k in range(150):                      # 150 exact copies of a 3 kb segment
+        at = 1000 + k * 1300
+        body[at:at + 1000] = unit[(k * 7) % 2000:(k * 7) % 2000 + 1000]
+    body[150_000:160_000] = np.resize(acgt[rng.integers(0, 4, size=5)], 10_000)
+    raw = np.concatenate([body, np.frombuffer(b"$", dtype=np.uint8)])
+    b = assert_matches_oracle(ctx, oracle, raw)
+    assert b.stats.num_levels > 1 and b.lcp.max() > 2000
+
+
+def test_protein_alphabet(ctx, oracle):
+    d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "uniprot.fa")
+    assert_matches_oracle(ctx, oracle, np.frombuffer(d.seq, dtype=np.uint8), is_dna=False)
+
+
+def test_text_without_sentinel_and_binary_bytes(ctx, oracle):
+    rng = np.random.default_rng(21)
+    raw = rng.integers(0, 256, size=50_000, dtype=np.uint8)          # all 256 byte values, zeros included
+    raw[(raw >= 97) & (raw <= 122)] = 0                               # (lowercase would be case-folded)
+    assert_matches_oracle(ctx, oracle, raw, is_dna=False)
+    raw = np.frombuffer(b"ABABABABABABABABABABABAB" * 40, dtype=np.uint8)   # no '$': proper-prefix ties
+    assert_matches_oracle(ctx, oracle, raw, is_dna=False)
+    raw = np.zeros(3000, dtype=np.uint8)                              # a run of 0x00 bytes
+    assert_matches_oracle(ctx, oracle, raw, is_dna=False)
+
+
+def test_elegans_like_5m(ctx, oracle):
+    x, _ = synth.syn_elegans(5_000_000, seed=2)
+    assert_matches_oracle(ctx, oracle, x.numpy())
+
+
+def test_ecoli_config_c2(ctx, oracle):
+    """BASELINE config C2: E. coli-sized (4.64 Mb) --dna, bit-exact vs the CPU build."""
+    x, _ = synth.syn_ecoli(4_641_652, seed=1)
+    b = assert_matches_oracle(ctx, oracle, x.numpy())
+    assert b.num_suffixes == 4_641_653
+
+
+# ---- device-resident API, shards --------------------------------------------------------------------
+def test_device_api_and_shards_concatenate(oracle):
+    x, _ = synth.syn_human(3_000_000, seed=5)
+    raw = x.numpy()
+    norm = oracle.normalize(raw, True)
+    sa, lcp, _ = oracle.build(norm, is_dna=True, threads=8)
+    db = sufr_amd.DeviceBuilder(0)
+    d_text = torch.from_numpy(raw).cuda()
+    fsa, flcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True)
+    assert np.array_equal(fsa.cpu().numpy().view(np.uint32), sa)
+    assert np.array_equal(flcp.cpu().numpy().view(np.uint32), lcp)
+    for shards in (2, 3, 8):
+        parts_sa, parts_lcp = [], []
+        for r in range(shards):
+            psa, plcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, shard_index=r,
+                                num_shards=shards)
+            psa = psa.cpu().numpy().view(np.uint32).copy(); plcp = plcp.cpu().numpy().view(np.uint32).copy()
+            if parts_sa and psa.size:      # boundary stitch: find_lcp(prev.last, this.first) (893-902)
+                prev = next(p for p in reversed(parts_sa) if p.size)
+                plcp[0] = sufr_amd.lcp_pair(norm, int(prev[-1]), int(psa[0]))
+            parts_sa.append(psa); parts_lcp.append(plcp)
+        assert np.array_equal(np.concatenate(parts_sa), sa)
+        assert np.array_equal(np.concatenate(parts_lcp), lcp)
+    db.close()
+
+
+# ---- BASELINE-sized property checks ---------------------------------------------------------------------
+def test_elegans_config_c3_properties(oracle):
+    """BASELINE config C3 size (100 Mb, 7 sequences): too big for the oracle in seconds, so check the
+    size-independent properties: permutation of the eligible positions, order and exact LCP on 2e5 sampled
+    adjacent ranks, plus the oracle on a prefix-range of the SA."""
+    x, _ = synth.syn_elegans(100_286_401, seed=2, device="cuda")
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True, raw_text=True)
+    st = db.stats.as_dict()
+    norm = oracle.normalize(x.cpu().numpy(), False)
+    check_sa_lcp_properties(norm, sa.cpu().numpy().view(np.uint32), lcp.cpu().numpy().view(np.uint32),
+                            is_dna=True, allow_ambiguity=False, sample=200_000, seed=1)
+    assert st["num_suffixes"] == 100_286_402
+    db.close()
