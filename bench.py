@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- suffixes sorted per second (SA + LCP) on the MI355X construction path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload human|elegans|ecoli] [--bases B]
+
+One *step* = one full pass of the hot path over one genome-sized batch that is already resident in
+HBM: text normalisation + byte histogram, radix partition on packed k-char prefix keys, the remaining
+LSD passes, the wave-level finisher and every re-keying level, ending with the complete SA and LCP
+arrays in HBM (libsufr_hip.so, sufr_hip_sort_device_u32).  Default workload: the configuration the
+BASELINE.json metric is quoted on, a GRCh38-sized genome (3.1 Gb, --dna --ignore-softmask, 256
+partitions); the real assembly is not available offline, so a seeded synthetic stand-in of the same size
+and repeat/masking structure is generated directly in HBM (sufr_amd/synth.py).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The genome is sharded by
+prefix-bucket range: every rank holds the text, derives the same splitters from the on-device k-mer
+histogram and builds only its bucket range; the only exchange is an all_gather of
+{first suffix, last suffix, count} per rank for the boundary-LCP stitch (sufr_builder.rs:893-902).
+Total work is fixed as N grows => "scaling": "strong".  value = suffixes of the whole genome / time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import sufr_amd
+from sufr_amd import synth
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (generator, default bases, sufr create flags, partitions, label)
+    "human": (synth.syn_human, 3_100_000_000, dict(is_dna=True, ignore_softmask=True), 256,
+              "syn_human 3.1 Gb stand-in for GRCh38, --dna --ignore-softmask -n 256 (BASELINE configs[3])"),
+    "elegans": (synth.syn_elegans, 100_286_401, dict(is_dna=True), 64,
+                "syn_elegans 100 Mb stand-in for C. elegans, --dna -n 64 (BASELINE configs[2])"),
+    "ecoli": (synth.syn_ecoli, 4_641_652, dict(is_dna=True), 16,
+              "syn_ecoli 4.6 Mb stand-in for E. coli K-12, --dna (BASELINE configs[1])"),
+}
+
+
+def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: float = 15.0):
+    """The oracle (C restatement of the reference algorithm, kind = "port") timed on this box's host
+    cores on a bounded prefix of the same workload."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from oracle_helper import Oracle
+    try:
+        o = Oracle(native=True)     # rebuilt here with -march=native
+    except Exception:
+        o = Oracle()
+    cores = os.cpu_count() or 1
+
+    def run(nb):
+        sample = np.concatenate([text_cpu[:nb], np.frombuffer(b"$", dtype=np.uint8)])
+        norm = o.normalize(sample, flags.get("ignore_softmask", False))
+        t0 = time.perf_counter()
+        _, _, st = o.build(norm, is_dna=flags.get("is_dna", False), num_partitions=partitions, threads=cores)
+        return st.num_suffixes, time.perf_counter() - t0, st
+
+    nb = min(text_cpu.size, 4_000_000)
+    s, dt, st = run(nb)
+    rate = s / max(dt, 1e-9)
+    want = int(min(text_cpu.size, max(nb, nb * (target_s / max(dt, 1e-3)) * 0.8), 400_000_000))
+    if want > nb * 2:
+        nb = want
+        s, dt, st = run(nb)
+        rate = s / max(dt, 1e-9)
+    return {"value": rate, "unit": "suffixes/s", "cores": cores, "kind": "port",
+            "sample": f"first {nb} bases of the same synthetic text (+'$'), {s} suffixes, "
+                      f"{partitions} partitions, {dt:.2f} s wall (partition {st.t_partition:.2f} s, "
+                      f"sort {st.t_sort:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("SUFR_BENCH_WORKLOAD", "human"), choices=sorted(WORKLOADS))
+    ap.add_argument("--bases", type=int, default=int(os.environ.get("SUFR_BENCH_BASES", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check SA/LCP properties on sampled ranks after timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    gen, default_bases, flags, partitions, label = WORKLOADS[args.workload]
+    bases = args.bases or default_bases
+    text, starts = gen(bases, device=dev)       # identical on every rank (same seed, same device type)
+    torch.cuda.synchronize()
+    n = text.numel()
+
+    builder = sufr_amd.DeviceBuilder(local_rank)
+    out_sa = out_lcp = None
+    stats_acc = []
+    def step():
+        nonlocal out_sa, out_lcp
+        sa, lcp = builder.sort(text, raw_text=True, shard_index=rank, num_shards=world, out_sa=out_sa,
+                               out_lcp=out_lcp, num_partitions=partitions, **flags)
+        return sa, lcp
+
+    # size the output arrays once (first call allocates n entries; later calls reuse them)
+    sa, lcp = step()
+    cap = int(builder.num_suffixes * 1.02) + 1024
+    out_sa = torch.empty(cap, dtype=torch.int32, device=dev)
+    out_lcp = torch.empty(cap, dtype=torch.int32, device=dev)
+    del sa, lcp
+    torch.cuda.empty_cache()
+    for _ in range(max(0, args.warmup)):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sa, lcp = step()
+        stats_acc.append(builder.stats.as_dict())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- boundary-LCP stitch across shards (the only exchange of the path) -------------------------
+    s_local = builder.num_suffixes
+    s_total = s_local
+    if world > 1:
+        mine = torch.tensor([int(sa[0].item()) & 0xFFFFFFFF if s_local else 0,
+                             int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0, s_local],
+                            dtype=torch.int64, device=dev)
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        counts = [int(v[2].item()) for v in allv]
+        s_total = sum(counts)
+        prev = [r for r in range(rank) if counts[r] > 0]
+        if prev and s_local:
+            a = int(allv[prev[-1]][1].item()); b = int(allv[rank][0].item())
+            # exact LCP of the two boundary suffixes on the normalised text (few characters: they differ
+            # inside the first radix digit)
+            ta = text[a:a + 64].cpu().numpy(); tb = text[b:b + 64].cpu().numpy()
+            na = sufr_amd.normalize(ta, flags.get("ignore_softmask", False)); nb_ = sufr_amd.normalize(tb, flags.get("ignore_softmask", False))
+            k = 0
+            while k < min(na.size, nb_.size) and na[k] == nb_[k]:
+                k += 1
+            lcp[0] = k
+
+    if args.verify:
+        sys.path.insert(0, str(ROOT / "tests"))
+        from oracle_helper import check_sa_lcp_properties
+        if world == 1:
+            norm = sufr_amd.normalize(text.cpu().numpy(), flags.get("ignore_softmask", False))
+            check_sa_lcp_properties(norm, sa.cpu().numpy().view(np.uint32), lcp.cpu().numpy().view(np.uint32),
+                                    is_dna=flags.get("is_dna", False), allow_ambiguity=False, sample=500_000)
+
+    if rank == 0:
+        keys = ["ms_total", "ms_normalize", "ms_hist_text", "ms_partition", "ms_passes", "ms_finish", "ms_deep"]
+        avg = {k: float(np.mean([s[k] for s in stats_acc])) for k in keys}
+        st = stats_acc[-1]
+        # radix-partition kernel (k_scatter_text): algorithmic bytes per launch = n (text) + 4 s (indices),
+        # SURVEY.md 8(d) / BASELINE.md section 4; s = suffixes this rank keeps
+        alg_bytes = n + 4 * st["num_suffixes"]
+        achieved = alg_bytes / (avg["ms_partition"] * 1e-3) / 1e9 if avg["ms_partition"] > 0 else 0.0
+        out = {
+            "metric": "suffixes sorted/sec (SA+LCP)",
+            "value": s_total * args.steps / dt,
+            "unit": "suffixes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8 text / u32 indices / u64 packed keys",
+            "data": "synthetic",
+            "config": {"workload": label, "text_len": n, "num_suffixes": s_total,
+                       "parallelism": f"prefix-bucket shards x{world}", "bits_per_char": st["bits_per_char"],
+                       "radix_passes": st["num_passes"], "digit_bits": st["digit_bits"],
+                       "levels": st["num_levels"], "deep_records": st["deep_records"]},
+            "roofline": {"kernel": "k_scatter_text (radix partition, first pass)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "ms": avg["ms_partition"]},
+            "device_ms": avg,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample_bases = min(bases, 400_000_000)
+            out["cpu_baseline"] = cpu_baseline(text[:sample_bases].cpu().numpy(), flags, partitions)
+        print(json.dumps(out), flush=True)
+    builder.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

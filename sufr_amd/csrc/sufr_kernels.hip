@@ -543,65 +543,190 @@ k_scan_bins(const uint32_t* __restrict__ bintot, uint32_t nbins, uint32_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_finish: wave-level finisher.  Input: records sorted by (segment, top C characters of the key).
-// A *group* is a maximal run of records equal in (segment, top C chars).  Wave t owns the groups
-// whose first record lies in slots [64t, 64t+64) and sees the 128-slot window [64t, 64t+128).
-//   * groups that end inside the window ("small") are completely ordered here:
-//       round 0 sorts by the whole K-character key; rounds r >= 1 fetch the next 8 raw text bytes of
-//       every still-tied suffix and sort by them (128-element bitonic network over 64 lanes x 2
-//       registers, __shfl-based), splitting tie groups until every suffix is alone;
-//     the LCP of a split is  depth + (common leading chars of the two keys / words)  -- exact.
-//   * groups that run past the window ("large") are appended to `large_heads` and re-keyed at depth
-//     + C by the next level (k_gather_keys ... k_finish again).
-// The LCP at a group's first record is the key-xor LCP with the record before it (another group),
-// i.e. the boundary LCP the reference recomputes in write() (sufr_builder.rs:893-902).
+// Run-length array.  R[p] = min(65535, length of the run of equal bytes that starts at p), runs end at
+// the end of the text.  Genomes built with --ignore-softmask are ~50 % 'N' in runs of hundreds to
+// millions of bytes; the reference walks through them byte by byte inside find_lcp
+// (sufr_builder.rs:301-331).  With R a whole run is compared in O(1) (see make_run_key).
+//   k_run_first: per 4096-byte tile, position of the first run end (0xffffffff if the tile has none)
+//   k_run_fill:  R for every position, looking at most 16 tiles ahead (the saturation horizon)
 // ---------------------------------------------------------------------------------------------
-struct Rec {
-    uint64_t k;     // sort word (key, or 8 text bytes big-endian)
-    uint32_t idx;   // suffix position
-    uint32_t gv;    // (group id << 8) | valid-byte count   -- primary / tertiary sort fields
-};
+static constexpr uint32_t RUN_SAT = 65535u;
 
-__device__ __forceinline__ bool rec_less(const Rec& a, const Rec& b)
+__global__ void __launch_bounds__(256)
+k_run_first(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ first_end)
 {
-    uint32_t ga = a.gv >> 8, gb = b.gv >> 8;
-    if (ga != gb) return ga < gb;
-    if (a.k != b.k) return a.k < b.k;
-    return (a.gv & 0xffu) < (b.gv & 0xffu);
-}
-
-__device__ __forceinline__ void cmpx_lane(Rec& r, int j, bool keep_min)
-{
-    Rec o;
-    o.k = shfl64_xor(r.k, j);
-    o.idx = __shfl_xor(r.idx, j, WAVE);
-    o.gv = __shfl_xor(r.gv, j, WAVE);
-    bool o_less = rec_less(o, r);
-    bool r_less = rec_less(r, o);
-    bool take = keep_min ? o_less : r_less;
-    if (take) r = o;
-}
-
-// sort the 128 records (slot = lane for r0, 64 + lane for r1) ascending
-__device__ __forceinline__ void bitonic128(Rec& r0, Rec& r1)
-{
-    const uint32_t ln = lane_id();
-    for (int k = 2; k <= 128; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) {
-                // partner is the other register of the same lane; k == 128 -> ascending
-                if (rec_less(r1, r0)) { Rec t = r0; r0 = r1; r1 = t; }
-            } else {
-                bool up0 = (k == 128) ? true : ((ln & k) == 0);
-                bool up1 = (k == 128) ? true : (((ln + 64) & k) == 0);
-                bool lower = (ln & j) == 0;
-                cmpx_lane(r0, j, lower == up0);
-                cmpx_lane(r1, j, lower == up1);
-            }
+    __shared__ uint32_t s_min;
+    if (threadIdx.x == 0) s_min = 0xffffffffu;
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * EPT;
+    uint32_t best = 0xffffffffu;
+    if (p0 < n) {
+        // bytes p0 .. p0+16 (the text is padded, reading past n is safe)
+        uint4 w = *reinterpret_cast<const uint4*>(text + p0);
+        uint32_t ws[5] = {w.x, w.y, w.z, w.w, (uint32_t)text[p0 + EPT]};
+#pragma unroll
+        for (int e = EPT - 1; e >= 0; e--) {
+            uint64_t p = p0 + e;
+            uint32_t a = (ws[e >> 2] >> (8 * (e & 3))) & 0xffu;
+            uint32_t b = (ws[(e + 1) >> 2] >> (8 * ((e + 1) & 3))) & 0xffu;
+            if (p < n && (p == n - 1 || a != b)) best = (uint32_t)p;
         }
+    }
+    if (best != 0xffffffffu) atomicMin(&s_min, best);
+    __syncthreads();
+    if (threadIdx.x == 0) first_end[blockIdx.x] = s_min;
+}
+
+__global__ void __launch_bounds__(256)
+k_run_fill(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ first_end,
+           uint32_t ntiles, uint16_t* __restrict__ R)
+{
+    __shared__ uint32_t s_thr[256];   // first run end inside each thread's 16 positions
+    __shared__ uint32_t s_next;       // first run end in the following tiles (within the horizon)
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * EPT;
+    uint32_t endpos[EPT];
+    uint32_t best = 0xffffffffu;
+    if (p0 < n) {
+        uint4 w = *reinterpret_cast<const uint4*>(text + p0);
+        uint32_t ws[5] = {w.x, w.y, w.z, w.w, (uint32_t)text[p0 + EPT]};
+#pragma unroll
+        for (int e = EPT - 1; e >= 0; e--) {
+            uint64_t p = p0 + e;
+            uint32_t a = (ws[e >> 2] >> (8 * (e & 3))) & 0xffu;
+            uint32_t b = (ws[(e + 1) >> 2] >> (8 * ((e + 1) & 3))) & 0xffu;
+            if (p < n && (p == n - 1 || a != b)) best = (uint32_t)p;
+            endpos[e] = best;           // nearest run end at or after p inside this thread's span
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) endpos[e] = 0xffffffffu;
+    }
+    s_thr[threadIdx.x] = best;
+    if (threadIdx.x == 0) {
+        uint32_t nx = 0xffffffffu;
+        for (uint32_t t = blockIdx.x + 1; t < ntiles && t <= blockIdx.x + 17 && nx == 0xffffffffu; t++)
+            nx = first_end[t];
+        s_next = nx;
+    }
+    __syncthreads();
+    // nearest run end after this thread's span: suffix-min over the later threads, then later tiles
+    uint32_t after = 0xffffffffu;
+    for (int t = threadIdx.x + 1; t < 256 && after == 0xffffffffu; t++) after = s_thr[t];
+    if (after == 0xffffffffu) after = s_next;
+    if (p0 < n) {
+        uint16_t out[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            uint64_t p = p0 + e;
+            uint32_t en = endpos[e] != 0xffffffffu ? endpos[e] : after;
+            uint32_t len = en == 0xffffffffu ? RUN_SAT : (uint32_t)min((uint64_t)RUN_SAT, (uint64_t)en - p + 1);
+            out[e] = (uint16_t)(p < n ? len : 0);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(R + p0);   // R is padded like the text
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pk[q] = (uint32_t)out[2 * q] | ((uint32_t)out[2 * q + 1] << 16);
+        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Run keys: the key format of every level below the first and of every tie round of the finisher.
+// All suffixes of a group agree on their first `q - idx` characters, in particular on c = text[q-1].
+// The key describes the text from q on as
+//     cls | gamma(rem + 1) [complemented if cls] | the characters after the run, b bits each
+//   rem = number of further bytes equal to c starting at q (0 if text[q] != c), saturating at 65535;
+//   x   = the byte after that run (end of text sorts lowest);   cls = (x > c).
+// Comparing  c^remA xA...  with  c^remB xB...:  if the runs differ in length, the shorter one is
+// smaller iff its x is below c -- so  {x < c, rem ascending} < {x > c, rem descending}; the Elias-gamma
+// code (L ones, a zero, L low bits) is order preserving and its complement reverses the order.
+// A saturated run has x == c, cls = 0 and continues with real text characters, which keeps the order.
+// The integer order of run keys therefore equals the suffix order, and a run of any length costs one
+// R lookup instead of a byte-by-byte walk.
+// ---------------------------------------------------------------------------------------------
+struct RunTok { uint32_t cls, rem; int tokbits; };
+
+__device__ __forceinline__ RunTok decode_run_token(uint64_t key)
+{
+    RunTok t;
+    t.cls = (uint32_t)(key >> 63);
+    uint64_t g = key << 1;
+    if (t.cls) g = ~g;
+    int L = g == ~0ull ? 63 : __clzll(~g);    // leading ones
+    if (L > 16) L = 16;                        // rem + 1 <= 65536
+    uint32_t low = L ? (uint32_t)((g << (L + 1)) >> (64 - L)) : 0u;
+    t.rem = ((1u << L) | low) - 1u;
+    t.tokbits = 2 + 2 * L;
+    return t;
+}
+
+// characters of common prefix described by two DIFFERENT keys of one group
+__device__ __forceinline__ uint32_t run_key_common(uint64_t a, uint64_t b, int bits)
+{
+    RunTok ta = decode_run_token(a), tb = decode_run_token(b);
+    if (ta.cls != tb.cls || ta.rem != tb.rem) return min(ta.rem, tb.rem);
+    uint64_t x = (a ^ b) << ta.tokbits;
+    return ta.rem + (x ? (uint32_t)(__clzll(x) / bits) : (uint32_t)((64 - ta.tokbits) / bits));
+}
+
+// characters covered by the top `sorted_bits` of a run key (what a group defined on them shares)
+__device__ __forceinline__ uint32_t run_key_advance(uint64_t key, int sorted_bits, int bits)
+{
+    RunTok t = decode_run_token(key);
+    int plain = sorted_bits - t.tokbits;
+    return t.rem + (plain > 0 ? (uint32_t)(plain / bits) : 0u);
+}
+
+__device__ __forceinline__ uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
+                                                 const uint16_t* __restrict__ R, const uint16_t* s_lut,
+                                                 int bits, uint64_t q)
+{
+    // q >= 1 and q <= n: the group shares at least one character
+    const uint32_t c = text[q - 1];
+    uint32_t rem = 0;
+    if (q < n && text[q] == c) rem = R[q];
+    const uint64_t after = q + rem;                    // <= n
+    const uint32_t x = after < n ? (uint32_t)text[after] : 0u;
+    const uint32_t cls = (after < n && x > c) ? 1u : 0u;
+    const uint32_t v = rem + 1u;
+    const int L = 31 - __clz(v);
+    const int glen = 2 * L + 1;
+    uint64_t g = (((1ull << L) - 1ull) << (L + 1)) | (uint64_t)(v & ((1u << L) - 1u));
+    if (cls) g = ~g & ((1ull << glen) - 1ull);
+    const int tokbits = 1 + glen;
+    uint64_t key = ((uint64_t)cls << 63) | (g << (63 - glen));
+    int shift = 64 - tokbits;
+    const int nch = shift / bits;
+    int j = 0;
+    while (j < nch) {
+        uint64_t w = (after + j < n) ? load_u64_unaligned(text + after + j) : 0ull;
+        int lim = min(8, nch - j);
+        for (int t = 0; t < lim; t++) {
+            uint32_t code = (after + j + t < n) ? (uint32_t)(s_lut[(w >> (8 * t)) & 0xffu] & 0x3ffu) : 0u;
+            shift -= bits;
+            key |= (uint64_t)code << shift;
+        }
+        j += lim;
+    }
+    return key;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finish: wave-level finisher.  Input: records sorted by (segment, top `sorted_bits` of the key).
+// A *group* is a maximal run of records equal in (segment, those bits).  Wave t owns the groups whose
+// first record lies in slots [64t, 64t+64) and sees the 128-slot window [64t, 64t+128).
+//   * groups that end inside the window ("small") are completely ordered here: round 0 ranks the
+//     members by their whole key; every further round re-keys the still-tied suffixes with a run key
+//     taken where their common prefix ends and ranks again, until every suffix is alone.  Ranking is a
+//     counting sort through wave-private LDS (rank = members that compare lower), cheap for the tiny
+//     groups that dominate; the LCP written at a split is depth + common characters of the two keys.
+//   * groups that run past the window ("large") are appended to `large_heads`; the next level re-keys
+//     them where their common prefix ends (k_group_extent / k_build_level / k_gather_keys).
+// The LCP at a group's first record is its key-derived LCP with the record before it (another group):
+// the boundary LCP the reference recomputes in write() (sufr_builder.rs:893-902).
+// Level 0 keys are plain packed characters (PLAIN0); deeper levels carry run keys.
+// ---------------------------------------------------------------------------------------------
 // inclusive max-scan over the 128 slots of (v0 @ slot lane, v1 @ slot 64+lane)
 __device__ __forceinline__ void maxscan128(int& v0, int& v1)
 {
@@ -616,11 +741,10 @@ __device__ __forceinline__ void maxscan128(int& v0, int& v1)
     v1 = max(v1, last0);
 }
 
-// suffix-min scan: for each slot, the smallest value at a slot strictly greater than it
+// for each slot, the smallest value found at a slot strictly greater than it (else `sentinel`)
 __device__ __forceinline__ void next_min128(int h0, int h1, int sentinel, int& n0, int& n1)
 {
     const int ln = (int)lane_id();
-    // inclusive suffix-min
     int s0 = h0, s1 = h1;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -630,33 +754,54 @@ __device__ __forceinline__ void next_min128(int h0, int h1, int sentinel, int& n
     }
     int first1 = __shfl(s1, 0, WAVE);
     s0 = min(s0, first1);
-    // exclusive: shift by one slot
     int e0 = __shfl_down(s0, 1, WAVE);
     int e1 = __shfl_down(s1, 1, WAVE);
     if (ln == 63) { e0 = first1; e1 = sentinel; }
     n0 = min(e0, sentinel); n1 = min(e1, sentinel);
 }
 
+__device__ __forceinline__ uint32_t plain_key_common(uint64_t a, uint64_t b, int bits, int K)
+{
+    uint64_t x = a ^ b;
+    return x ? (uint32_t)(__clzll(x) / bits) : (uint32_t)K;
+}
+
 template <bool DEEP>
 __global__ void __launch_bounds__(256)
 k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
-         const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos, uint32_t m,
-         const uint8_t* __restrict__ text, uint64_t n, uint64_t depth, KeyParams kp, int group_shift,
+         const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
+         const uint32_t* __restrict__ segdepth, uint32_t m,
+         const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ R,
+         const uint16_t* __restrict__ glut, KeyParams kp, int sorted_bits,
          uint32_t* __restrict__ SA, uint32_t* __restrict__ LCP,
          uint32_t* __restrict__ large_heads, uint32_t* __restrict__ large_count)
 {
+    __shared__ uint64_t sh_key[4][128];
+    __shared__ uint32_t sh_idx[4][128];
+    __shared__ uint32_t sh_gid[4][128];
+    __shared__ uint16_t s_lut[256];
+    for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
+    __syncthreads();
+
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const uint32_t base = wave * 64;
     if (base >= m) return;
+    const int wv = threadIdx.x >> 6;
+    volatile uint64_t* sk = sh_key[wv];
+    volatile uint32_t* si = sh_idx[wv];
+    volatile uint32_t* sg = sh_gid[wv];
     const int ln = (int)lane_id();
+    const int group_shift = 64 - sorted_bits;
     const uint32_t j0 = base + ln, j1 = base + 64 + ln;
     const bool in0 = j0 < m, in1 = j1 < m;
 
-    Rec r0, r1;
-    r0.k = in0 ? keys[j0] : ~0ull;  r0.idx = in0 ? idxs[j0] : 0u;
-    r1.k = in1 ? keys[j1] : ~0ull;  r1.idx = in1 ? idxs[j1] : 0u;
+    uint64_t k0 = in0 ? keys[j0] : ~0ull, k1 = in1 ? keys[j1] : ~0ull;
+    uint32_t i0 = in0 ? idxs[j0] : 0u, i1 = in1 ? idxs[j1] : 0u;
     uint32_t sg0 = 0, sg1 = 0;
     if (DEEP) { sg0 = in0 ? segs[j0] : 0xffffffffu; sg1 = in1 ? segs[j1] : 0xffffffffu; }
+    // depth at which this record's key was taken (per segment below level 0)
+    uint32_t dd0 = 0, dd1 = 0;
+    if (DEEP) { dd0 = in0 ? segdepth[sg0] : 0u; dd1 = in1 ? segdepth[sg1] : 0u; }
 
     // record before the window (slot -1) and after it (slot 128)
     uint64_t kprev = 0, knext = 0; uint32_t sprev = 0, snext = 0;
@@ -665,204 +810,157 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     if (has_prev) { kprev = keys[base - 1]; if (DEEP) sprev = segs[base - 1]; }
     if (has_next) { knext = keys[base + 128]; if (DEEP) snext = segs[base + 128]; }
 
-    // ---- head flags (group = equal segment and equal top-C characters) ----------------------
-    uint64_t p0 = shfl64_up1(r0.k), p1 = shfl64_up1(r1.k);
+    // ---- head flags (group = equal segment and equal sorted bits) -------------------------------
+    uint64_t p0 = shfl64_up1(k0), p1 = shfl64_up1(k1);
     uint32_t ps0 = __shfl_up(sg0, 1, WAVE), ps1 = __shfl_up(sg1, 1, WAVE);
-    uint64_t last0k = shfl64(r0.k, 63); uint32_t last0s = __shfl(sg0, 63, WAVE);
+    uint64_t last0k = shfl64(k0, 63); uint32_t last0s = __shfl(sg0, 63, WAVE);
     if (ln == 0) { p0 = kprev; ps0 = sprev; p1 = last0k; ps1 = last0s; }
-    bool segdiff0 = DEEP && (ps0 != sg0), segdiff1 = DEEP && (ps1 != sg1);
-    bool h0 = !in0 || (ln == 0 && !has_prev) || segdiff0 || ((p0 >> group_shift) != (r0.k >> group_shift));
-    bool h1 = !in1 || segdiff1 || ((p1 >> group_shift) != (r1.k >> group_shift));
-    // is slot 128 a head?  (needed to know whether a group ends exactly at the window end)
-    uint64_t last1k = shfl64(r1.k, 63); uint32_t last1s = __shfl(sg1, 63, WAVE);
-    bool h128 = !has_next || (DEEP && snext != last1s) || ((knext >> group_shift) != (last1k >> group_shift));
+    const bool segdiff0 = DEEP && (ps0 != sg0), segdiff1 = DEEP && (ps1 != sg1);
+    const bool h0 = !in0 || (ln == 0 && !has_prev) || segdiff0 || ((p0 >> group_shift) != (k0 >> group_shift));
+    const bool h1 = !in1 || segdiff1 || ((p1 >> group_shift) != (k1 >> group_shift));
+    uint64_t last1k = shfl64(k1, 63); uint32_t last1s = __shfl(sg1, 63, WAVE);
+    const bool h128 = !has_next || (DEEP && snext != last1s) ||
+                      ((knext >> group_shift) != (last1k >> group_shift));
 
-    // boundary LCP of a head with the record before it (different group => differs inside the key)
-    // and first-of-segment flags (their LCP belongs to the parent level)
-    uint32_t blcp0 = 0, blcp1 = 0;
-    {
-        uint64_t x0 = p0 ^ r0.k, x1 = p1 ^ r1.k;
-        blcp0 = x0 ? (uint32_t)(__clzll(x0) / kp.b) : (uint32_t)kp.K;
-        blcp1 = x1 ? (uint32_t)(__clzll(x1) / kp.b) : (uint32_t)kp.K;
-    }
-    const bool first0 = (ln == 0 && !has_prev) || segdiff0;   // no LCP to emit from this level
+    // first record of a segment (or of everything): its LCP belongs to the parent level / is 0
+    const bool first0 = (ln == 0 && !has_prev) || segdiff0;
     const bool first1 = segdiff1;
+    // LCP of a head with the record before it (same segment, different group => keys differ)
+    uint32_t lcp0 = 0, lcp1 = 0;
+    if (!first0 && in0) lcp0 = dd0 + (DEEP ? run_key_common(p0, k0, kp.b) : plain_key_common(p0, k0, kp.b, kp.K));
+    if (!first1 && in1) lcp1 = dd1 + (DEEP ? run_key_common(p1, k1, kp.b) : plain_key_common(p1, k1, kp.b, kp.K));
 
-    // ---- group ids: head slot of the group each slot belongs to ------------------------------
+    // ---- group ids: head slot of the group each slot belongs to -----------------------------------
     int g0 = h0 ? ln : -1, g1 = h1 ? (64 + ln) : -1;
     maxscan128(g0, g1);
-    int hh0 = h0 ? ln : 1000, hh1 = h1 ? (64 + ln) : 1000;
     int nx0, nx1;
-    next_min128(hh0, hh1, h128 ? 128 : 1000, nx0, nx1);   // next head slot after each slot
-    // group end for each slot = next head after the slot's own position scanning forward;
-    // for a slot inside a group that is the first head found after it.
+    next_min128(h0 ? ln : 1000, h1 ? (64 + ln) : 1000, h128 ? 128 : 1000, nx0, nx1);
     const bool own0 = in0 && g0 >= 0 && g0 < 64, own1 = in1 && g1 >= 0 && g1 < 64;
-    // end of the group that slot belongs to: next head after this slot, propagated: every member
-    // sees the same "next head after me" only if no head lies between -- true by definition.
     const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
-    // large groups: reported once, by their head slot
-    if (own0 && h0 && !small0) {
+    if (own0 && h0 && !small0) {            // a large group is reported once, by its head slot
         uint32_t at = atomicAdd(large_count, 1u);
         large_heads[at] = j0;
-        if (!first0) LCP[DEEP ? opos[j0] : j0] = (uint32_t)depth + blcp0;
+        if (!first0) LCP[DEEP ? opos[j0] : j0] = lcp0;
         else if (!DEEP) LCP[j0] = 0;
     }
-    // (a head can never sit in r1 and be owned: owned heads are slots < 64)
+    bool act0 = small0 && !(h0 && nx0 == ln + 1);     // member of a small group with > 1 records
+    bool act1 = small1 && !(h1 && nx1 == 64 + ln + 1);
+    uint32_t gid0 = act0 ? (uint32_t)g0 : (0x10000u | (uint32_t)ln);
+    uint32_t gid1 = act1 ? (uint32_t)g1 : (0x10000u | (uint32_t)(64 + ln));
 
-    // group size > 1 ?
-    const bool multi0 = small0 && !(h0 && nx0 == ln + 1);
-    const bool multi1 = small1 && !(h1 && nx1 == 64 + ln + 1);
-    // sort group id: members of a small multi-record group share their head slot, everything
-    // else is pinned to its own slot.
-    uint32_t sgid0 = multi0 ? (uint32_t)g0 : (uint32_t)ln;
-    uint32_t sgid1 = multi1 ? (uint32_t)g1 : (uint32_t)(64 + ln);
-    uint32_t lcp0 = (uint32_t)depth + blcp0, lcp1 = (uint32_t)depth + blcp1;  // valid at heads
-
-    bool act0 = multi0, act1 = multi1;
-    if (__ballot(act0 || act1)) {
-        // ---- round 0: order by the full K-character key ------------------------------------
-        r0.gv = (sgid0 << 8) | 8u; r1.gv = (sgid1 << 8) | 8u;
-        bitonic128(r0, r1);
-        uint64_t d = depth + (uint64_t)kp.K;     // chars known equal inside a tie group
-        int round = 0;
-        // distinct suffixes must separate within n bytes; the bound only guards against a hang
-        const uint64_t max_round = n / 8 + 8;
-        for (;;) {
-            if ((uint64_t)round > max_round) break;
-            // split tie groups: slot j starts a new group if it differs from slot j-1
-            Rec q0, q1;
-            q0.k = shfl64_up1(r0.k); q0.gv = __shfl_up(r0.gv, 1, WAVE);
-            q1.k = shfl64_up1(r1.k); q1.gv = __shfl_up(r1.gv, 1, WAVE);
-            uint64_t l0k = shfl64(r0.k, 63); uint32_t l0g = __shfl(r0.gv, 63, WAVE);
-            if (ln == 0) { q0.k = 0; q0.gv = 0xffffffffu; q1.k = l0k; q1.gv = l0g; }
-            bool same0 = act0 && ((q0.gv >> 8) == (r0.gv >> 8));
-            bool same1 = act1 && ((q1.gv >> 8) == (r1.gv >> 8));
-            // tie <=> same group, equal word, both fully valid
-            bool tie0 = same0 && q0.k == r0.k && (q0.gv & 0xffu) == 8u && (r0.gv & 0xffu) == 8u;
-            bool tie1 = same1 && q1.k == r1.k && (q1.gv & 0xffu) == 8u && (r1.gv & 0xffu) == 8u;
-            if (same0 && !tie0) {
-                uint64_t x = q0.k ^ r0.k;
-                uint32_t common = round == 0 ? (x ? (uint32_t)(__clzll(x) / kp.b) : (uint32_t)kp.K)
-                                             : (x ? (uint32_t)(__clzll(x) >> 3) : 8u);
-                uint32_t va = q0.gv & 0xffu, vb = r0.gv & 0xffu;
-                if (round > 0) common = min(common, min(va, vb));
-                lcp0 = (uint32_t)(round == 0 ? depth : d) + common;
+    bool plain = !DEEP;                       // format of the keys currently held
+    const uint64_t max_round = n + 8;        // distinct suffixes separate within n characters
+    for (uint64_t round = 0; __ballot(act0 || act1) != 0ull && round < max_round; round++) {
+        // ---- rank every active record inside its group (counting sort through LDS) ----------------
+        sk[ln] = k0; sk[64 + ln] = k1; sg[ln] = gid0; sg[64 + ln] = gid1;
+        uint32_t np0 = (uint32_t)ln, np1 = (uint32_t)(64 + ln);
+        if (act0) {
+            uint32_t cnt = 0;
+            for (uint32_t t = gid0; t < 128u && sg[t] == gid0; t++) {
+                uint64_t kt = sk[t];
+                cnt += (kt < k0 || (kt == k0 && t < (uint32_t)ln)) ? 1u : 0u;
             }
-            if (same1 && !tie1) {
-                uint64_t x = q1.k ^ r1.k;
-                uint32_t common = round == 0 ? (x ? (uint32_t)(__clzll(x) / kp.b) : (uint32_t)kp.K)
-                                             : (x ? (uint32_t)(__clzll(x) >> 3) : 8u);
-                uint32_t va = q1.gv & 0xffu, vb = r1.gv & 0xffu;
-                if (round > 0) common = min(common, min(va, vb));
-                lcp1 = (uint32_t)(round == 0 ? depth : d) + common;
-            }
-            // new group ids: head = start of a tie run
-            int ng0 = (act0 && tie0) ? -1 : ln, ng1 = (act1 && tie1) ? -1 : (64 + ln);
-            maxscan128(ng0, ng1);
-            // a slot stays active iff its tie run has more than one member
-            bool nt0 = tie0, nt1 = tie1;                   // I tie with my predecessor
-            bool s0n = __shfl_down((int)nt0, 1, WAVE);      // my successor ties with me
-            bool s1n = __shfl_down((int)nt1, 1, WAVE);
-            bool f1 = __shfl((int)nt1, 0, WAVE);
-            if (ln == 63) { s0n = f1; s1n = false; }
-            act0 = act0 && (nt0 || s0n);
-            act1 = act1 && (nt1 || s1n);
-            sgid0 = act0 ? (uint32_t)ng0 : (uint32_t)ln;
-            sgid1 = act1 ? (uint32_t)ng1 : (uint32_t)(64 + ln);
-            if (!__ballot(act0 || act1)) break;
-            // ---- next round: fetch 8 raw text bytes at depth d for the tied suffixes ---------
-            if (round > 0) d += 8;
-            round++;
-            uint32_t v0 = 8, v1 = 8;
-            uint64_t w0 = 0, w1 = 0;
-            if (act0) {
-                uint64_t p = (uint64_t)r0.idx + d;
-                v0 = p >= n ? 0u : (uint32_t)min((uint64_t)8, n - p);
-                w0 = v0 ? __builtin_bswap64(load_u64_unaligned(text + p)) : 0ull;
-                if (v0 < 8) w0 &= v0 ? (~0ull << (8 * (8 - v0))) : 0ull;
-            }
-            if (act1) {
-                uint64_t p = (uint64_t)r1.idx + d;
-                v1 = p >= n ? 0u : (uint32_t)min((uint64_t)8, n - p);
-                w1 = v1 ? __builtin_bswap64(load_u64_unaligned(text + p)) : 0ull;
-                if (v1 < 8) w1 &= v1 ? (~0ull << (8 * (8 - v1))) : 0ull;
-            }
-            r0.k = w0; r0.gv = (sgid0 << 8) | v0;
-            r1.k = w1; r1.gv = (sgid1 << 8) | v1;
-            // skip the sort when every tie group read identical full words (deep repeats)
-            uint64_t hk0 = shfl64_up1(r0.k), hk1 = shfl64_up1(r1.k);
-            uint32_t hg0 = __shfl_up(r0.gv, 1, WAVE), hg1 = __shfl_up(r1.gv, 1, WAVE);
-            uint64_t e0k = shfl64(r0.k, 63); uint32_t e0g = __shfl(r0.gv, 63, WAVE);
-            if (ln == 0) { hk0 = r0.k; hg0 = r0.gv; hk1 = e0k; hg1 = e0g; }
-            bool diff0 = act0 && (hg0 >> 8) == (r0.gv >> 8) && (hk0 != r0.k || (hg0 & 0xffu) != (r0.gv & 0xffu));
-            bool diff1 = act1 && (hg1 >> 8) == (r1.gv >> 8) && (hk1 != r1.k || (hg1 & 0xffu) != (r1.gv & 0xffu));
-            if (__ballot(diff0 || diff1)) bitonic128(r0, r1);
+            np0 = gid0 + cnt;
         }
+        if (act1) {
+            uint32_t cnt = 0;
+            for (uint32_t t = gid1; t < 128u && sg[t] == gid1; t++) {
+                uint64_t kt = sk[t];
+                cnt += (kt < k1 || (kt == k1 && t < (uint32_t)(64 + ln))) ? 1u : 0u;
+            }
+            np1 = gid1 + cnt;
+        }
+        // every lane has finished reading (one wave, in-order LDS); move the records
+        if (act0) { sk[np0] = k0; si[np0] = i0; }
+        if (act1) { sk[np1] = k1; si[np1] = i1; }
+        if (act0) { k0 = sk[ln]; i0 = si[ln]; }
+        if (act1) { k1 = sk[64 + ln]; i1 = si[64 + ln]; }
+        // ---- split: slot j starts a new group if its key differs from slot j-1 of its group -------
+        uint64_t q0 = (act0 && ln > 0) ? sk[ln - 1] : 0ull;
+        uint64_t q1 = act1 ? sk[63 + ln] : 0ull;
+        const bool same0 = act0 && (uint32_t)ln > gid0;
+        const bool same1 = act1 && (uint32_t)(64 + ln) > gid1;
+        const bool tie0 = same0 && q0 == k0, tie1 = same1 && q1 == k1;
+        if (same0 && !tie0) lcp0 = dd0 + (plain ? plain_key_common(q0, k0, kp.b, kp.K) : run_key_common(q0, k0, kp.b));
+        if (same1 && !tie1) lcp1 = dd1 + (plain ? plain_key_common(q1, k1, kp.b, kp.K) : run_key_common(q1, k1, kp.b));
+        int ng0 = tie0 ? -1 : ln, ng1 = tie1 ? -1 : (64 + ln);
+        maxscan128(ng0, ng1);
+        bool s0n = __shfl_down((int)tie0, 1, WAVE), s1n = __shfl_down((int)tie1, 1, WAVE);
+        bool f1 = __shfl((int)tie1, 0, WAVE);
+        if (ln == 63) { s0n = f1; s1n = false; }
+        act0 = act0 && (tie0 || s0n);
+        act1 = act1 && (tie1 || s1n);
+        gid0 = act0 ? (uint32_t)ng0 : (0x10000u | (uint32_t)ln);
+        gid1 = act1 ? (uint32_t)ng1 : (0x10000u | (uint32_t)(64 + ln));
+        // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
+        if (act0) {
+            dd0 += plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b);
+            k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0);
+        }
+        if (act1) {
+            dd1 += plain ? (uint32_t)kp.K : run_key_advance(k1, 64, kp.b);
+            k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1);
+        }
+        plain = false;
     }
-    // ---- write the owned, completely ordered slots ----------------------------------------------
+    // ---- write the owned, completely ordered slots ------------------------------------------------
     if (small0) {
         uint32_t o = DEEP ? opos[j0] : j0;
-        SA[o] = r0.idx;
-        if (!(first0 && h0)) LCP[o] = lcp0;
+        SA[o] = i0;
+        if (!first0) LCP[o] = lcp0;
         else if (!DEEP) LCP[o] = 0;
     }
     if (small1) {
         uint32_t o = DEEP ? opos[j1] : j1;
-        SA[o] = r1.idx;
-        if (!(first1 && h1)) LCP[o] = lcp1;
+        SA[o] = i1;
+        if (!first1) LCP[o] = lcp1;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Deep levels: large groups are re-keyed at depth + C.
+// Deeper levels: large groups are re-keyed where their common prefix ends.
 // ---------------------------------------------------------------------------------------------
-// keys[e] = packed K-character key of suffix idx[e] starting `depth` characters in.
+// keys[e] = run key of suffix idx[e] taken segdepth[seg[e]] characters in
 __global__ void __launch_bounds__(256)
-k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
-              const uint32_t* __restrict__ idx, uint32_t m, uint64_t depth, KeyParams kp,
-              uint64_t* __restrict__ keys)
+k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ R,
+              const uint16_t* __restrict__ glut, const uint32_t* __restrict__ idx,
+              const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth, uint32_t m,
+              KeyParams kp, uint64_t* __restrict__ keys)
 {
     __shared__ uint16_t s_lut[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= m) return;
-    uint64_t p = (uint64_t)idx[e] + depth;
-    uint64_t key = 0;
-    int j = 0;
-    while (j < kp.K) {
-        uint64_t w = (p + j < n) ? load_u64_unaligned(text + p + j) : 0ull;
-        int lim = min(8, kp.K - j);
-        for (int t = 0; t < lim; t++) {
-            uint32_t c = (p + j + t < n) ? (uint32_t)(s_lut[(w >> (8 * t)) & 0xffu] & 0x3ffu) : 0u;
-            key = (key << kp.b) | c;
-        }
-        j += lim;
-    }
-    keys[e] = key << (64 - kp.K * kp.b);
+    keys[e] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]]);
 }
 
-// size of every large group: upper bound of (segment, top-C chars) in the sorted records
+// size of every large group (upper bound of (segment, sorted bits) in the sorted records) and the depth
+// at which its members will be re-keyed: parent depth + characters covered by the sorted bits
 template <bool DEEP>
 __global__ void __launch_bounds__(256)
-k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ segs, uint32_t m,
-               int group_shift, const uint32_t* __restrict__ heads, uint32_t L,
-               uint32_t* __restrict__ sizes, uint32_t* __restrict__ maxsize)
+k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ segs,
+               const uint32_t* __restrict__ segdepth, uint32_t m, int sorted_bits, KeyParams kp,
+               const uint32_t* __restrict__ heads, uint32_t L, uint32_t* __restrict__ sizes,
+               uint32_t* __restrict__ newdepth, uint32_t* __restrict__ maxsize)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= L) return;
+    const int group_shift = 64 - sorted_bits;
     uint32_t h = heads[k];
-    uint64_t top = keys[h] >> group_shift;
+    uint64_t hk = keys[h];
+    uint64_t top = hk >> group_shift;
     uint32_t sg = DEEP ? segs[h] : 0u;
     uint32_t lo = h + 1, hi = m;    // first position > h that is not in the group
     while (lo < hi) {
         uint32_t mid = lo + (hi - lo) / 2;
         bool in_group = (!DEEP || segs[mid] == sg) && ((keys[mid] >> group_shift) == top);
-        // records are sorted by (seg, top): everything in (h, end) is in the group
         if (in_group) lo = mid + 1; else hi = mid;
     }
     uint32_t sz = lo - h;
     sizes[k] = sz;
+    newdepth[k] = DEEP ? segdepth[sg] + run_key_advance(hk, sorted_bits, kp.b)
+                       : (uint32_t)(sorted_bits / kp.b);
     atomicMax(maxsize, sz);
 }
 

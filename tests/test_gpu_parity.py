@@ -122,11 +122,39 @@ def test_empty_text(ctx):
     assert b.num_suffixes == 0
 
 
+def _break_long_n_runs(raw: np.ndarray) -> np.ndarray:
+    """Keep every N run shorter than 1000: the reference's N-run shortcut (sufr_builder.rs:302-307, only
+    active with allow_ambiguity) makes its own output approximate and merge-order dependent once two runs
+    of >= 1000 N exist, so bit-exact comparison with it is only meaningful below that length."""
+    raw = raw.copy()
+    npos = np.nonzero((raw == ord("N")) | (raw == ord("n")))[0]
+    raw[npos[::500]] = ord("C")
+    return raw
+
+
 @pytest.mark.parametrize("soft", [False, True])
 @pytest.mark.parametrize("amb", [False, True])
 def test_softmask_ambiguity_delimiters(ctx, oracle, soft, amb):
     x, starts = synth.syn_human(400_000, seed=11)
-    assert_matches_oracle(ctx, oracle, x.numpy(), ignore_softmask=soft, allow_ambiguity=amb)
+    raw = x.numpy()
+    if amb:
+        raw = _break_long_n_runs(raw)
+        if soft:   # lowercase becomes N as well: keep those runs short too
+            low = np.nonzero((raw >= 97) & (raw <= 122))[0]
+            raw[low[::400]] &= 0xDF
+    assert_matches_oracle(ctx, oracle, raw, ignore_softmask=soft, allow_ambiguity=amb)
+
+
+def test_allow_ambiguity_long_n_runs_are_exact(ctx):
+    """With several N runs >= 1000 the reference is approximate (see above); the GPU path returns the exact
+    order and exact LCP, checked against the naive witness."""
+    rng = np.random.default_rng(4)
+    body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=9000)].copy()
+    body[500:1700] = ord("N"); body[3000:4200] = ord("N"); body[6000:7500] = ord("N")
+    raw = np.concatenate([body, np.frombuffer(b"$", dtype=np.uint8)])
+    b = gpu_build(ctx, raw, allow_ambiguity=True)
+    sa, lcp = naive_sa_lcp(raw, True, True)
+    assert np.array_equal(b.suffix_array, sa) and np.array_equal(b.lcp, lcp)
 
 
 def test_only_ineligible(ctx, oracle):
@@ -222,5 +250,5 @@ def test_elegans_config_c3_properties(oracle):
     norm = oracle.normalize(x.cpu().numpy(), False)
     check_sa_lcp_properties(norm, sa.cpu().numpy().view(np.uint32), lcp.cpu().numpy().view(np.uint32),
                             is_dna=True, allow_ambiguity=False, sample=200_000, seed=1)
-    assert st["num_suffixes"] == 100_286_402
+    assert st["num_suffixes"] == 100_286_402 - 6      # 6 delimiter positions are not suffix starts
     db.close()
