@@ -16,7 +16,8 @@ struct KeyParams {
     int K;          // characters per 64-bit key  = 64 / b
     int dchars;     // characters per radix digit = max(1, 12 / b)
     int dbits;      // bits per radix digit       = b * dchars  (<= 12)
-    uint32_t nbins; // 1 << dbits
+    uint32_t raw_bins; // 1 << dbits: nominal digit values
+    uint32_t nbins;    // digit values after the dense remap (== raw_bins when there is no remap)
     int top_shift;  // 64 - dbits: the most significant digit (shard selector)
 };
 

@@ -115,24 +115,102 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 // so integer order of codes == raw byte order); 0 = "past the end of the text" (sorts lowest,
 // sufr_builder.rs:372-379).  key = K codes of b bits, first character in the most significant bits.
 // lut[byte] = code | 0x8000 if a suffix may START with that byte (eligibility, 446-449).
+//
+// Radix digits are dchars whole characters (dbits = b * dchars <= 12 bits).  Only a fraction of the
+// 2^dbits nominal digit values occurs in a text (DNA: ~450 of 4096 4-mers), so digits are mapped
+// through `remap` (monotone, built from the set of dchars-mers present) to a dense range [0, nbins):
+// every per-bin LDS array, the bin scan and the ballot loop of the stable ranking shrink accordingly.
 // ---------------------------------------------------------------------------------------------
 struct TileKeys {
     uint64_t key[EPT];
     uint32_t elig;  // bit e set: position e of this thread is a suffix start inside [0,n)
 };
 
-// Stage one text tile (TILE positions + halo) into LDS as raw bytes.
+__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t raw_mask, const uint16_t* s_remap)
+{
+    uint32_t r = (uint32_t)(key >> shift) & raw_mask;
+    return s_remap ? (uint32_t)s_remap[r] : r;
+}
+
+__device__ __forceinline__ void load_lut(const uint16_t* __restrict__ glut, uint16_t* s_lut)
+{
+    for (int i = threadIdx.x; i < 256; i += THREADS) s_lut[i] = glut[i];
+}
+
+__device__ __forceinline__ const uint16_t* load_remap(const uint16_t* __restrict__ gremap, uint16_t* s_remap,
+                                                      uint32_t raw_bins)
+{
+    if (!gremap) return nullptr;
+    for (uint32_t i = threadIdx.x; i < raw_bins; i += THREADS) s_remap[i] = gremap[i];
+    return s_remap;
+}
+
+// ---- tile staging, B = bits per character known at compile time (fast path, B <= 7) --------------
+// Each thread converts 16 raw bytes to code bytes (code | 0x80 if eligible, 0 past the end) and stores
+// them with one 16-byte LDS write; keys are then built from 16-byte LDS reads held in registers, so the
+// LDS sees no strided byte traffic.
+template <int B>
+__device__ __forceinline__ void stage_code_tile(const uint8_t* __restrict__ text, uint64_t tile0, uint64_t n,
+                                                const uint16_t* s_lut, uint8_t* s_code)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(text + tile0);  // text is padded; tile0 % 16 == 0
+    uint4* dst = reinterpret_cast<uint4*>(s_code);
+    for (int v = threadIdx.x; v < (TILE + HALO) / 16; v += THREADS) {
+        uint4 w = src[v];
+        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        const uint64_t pos0 = tile0 + (uint64_t)v * 16;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t y = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t l = s_lut[(ws[k] >> (8 * j)) & 0xffu];
+                uint32_t c = (pos0 + k * 4 + j < n) ? ((l & 0x7fu) | ((l >> 8) & 0x80u)) : 0u;
+                y |= c << (8 * j);
+            }
+            ws[k] = y;
+        }
+        dst[v] = make_uint4(ws[0], ws[1], ws[2], ws[3]);
+    }
+}
+
+template <int B>
+__device__ __forceinline__ void build_tile_keys_fast(const uint8_t* s_code, TileKeys& tk)
+{
+    constexpr int K = 64 / B;
+    constexpr int NV = (EPT + K + 15) / 16;
+    constexpr int low = 64 - K * B;
+    uint32_t w[NV * 4];
+    const uint4* src = reinterpret_cast<const uint4*>(s_code + threadIdx.x * EPT);
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        uint4 q = src[v];
+        w[4 * v] = q.x; w[4 * v + 1] = q.y; w[4 * v + 2] = q.z; w[4 * v + 3] = q.w;
+    }
+    uint64_t key = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) key = (key << B) | (uint64_t)((w[j >> 2] >> (8 * (j & 3))) & 0x7fu);
+    key <<= low;
+    tk.elig = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        tk.key[e] = key;
+        if ((w[e >> 2] >> (8 * (e & 3))) & 0x80u) tk.elig |= 1u << e;
+        constexpr int dummy = 0; (void)dummy;
+        uint64_t c = (w[(e + K) >> 2] >> (8 * ((e + K) & 3))) & 0x7fu;
+        key = (key << B) | (c << low);
+    }
+}
+
+// ---- generic path (any b): raw bytes staged in LDS, per-byte lookups ---------------------------------
 __device__ __forceinline__ void stage_text_tile(const uint8_t* __restrict__ text, uint64_t tile0,
                                                 uint8_t* s_text)
 {
-    // text is padded: reading TILE + HALO bytes from tile0 is always in bounds.
-    const uint4* src = reinterpret_cast<const uint4*>(text + tile0);  // tile0 % 16 == 0
+    const uint4* src = reinterpret_cast<const uint4*>(text + tile0);
     uint4* dst = reinterpret_cast<uint4*>(s_text);
     for (int v = threadIdx.x; v < (TILE + HALO) / 16; v += THREADS) dst[v] = src[v];
 }
 
-// Each thread owns EPT consecutive positions tile0 + threadIdx.x*EPT + e and builds their keys
-// with a rolling update: key(i+1) = (key(i) << b) | code(i+K) << (64 - K*b).
 __device__ __forceinline__ void build_tile_keys(const uint8_t* s_text, const uint16_t* s_lut,
                                                 uint64_t tile0, uint64_t n, int b, int K, TileKeys& tk)
 {
@@ -157,44 +235,86 @@ __device__ __forceinline__ void build_tile_keys(const uint8_t* s_text, const uin
     }
 }
 
-__device__ __forceinline__ void load_lut(const uint16_t* __restrict__ glut, uint16_t* s_lut)
+template <int B>
+__device__ __forceinline__ void tile_keys(const uint8_t* __restrict__ text, uint64_t tile0, uint64_t n,
+                                          const uint16_t* s_lut, uint8_t* s_tile, const KeyParams& kp,
+                                          TileKeys& tk)
 {
-    for (int i = threadIdx.x; i < 256; i += THREADS) s_lut[i] = glut[i];
+    if constexpr (B > 0) {
+        stage_code_tile<B>(text, tile0, n, s_lut, s_tile);
+        __syncthreads();
+        build_tile_keys_fast<B>(s_tile, tk);
+    } else {
+        stage_text_tile(text, tile0, s_tile);
+        __syncthreads();
+        build_tile_keys(s_tile, s_lut, tile0, n, kp.b, kp.K, tk);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_hist_text: per-workgroup digit histogram of the first radix pass, streaming the text.
-// Row w of `table` (layout [workgroup][bin]) counts the digit `(key >> shift) & mask` of every
-// eligible position of workgroup w's text chunk whose TOP digit lies in [top_lo, top_hi)
-// (the shard filter used when a genome is split over GPUs by prefix-bucket range).
+// k_digit_presence: which dchars-mers (top-digit values of the key of EVERY text position) occur.
+// flags[v] = 1 for every value seen; the host turns the flags into the dense `remap`.
 // ---------------------------------------------------------------------------------------------
+template <int B>
 __global__ void __launch_bounds__(THREADS)
-k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
-            KeyParams kp, int shift, uint64_t chunk, uint32_t top_lo, uint32_t top_hi,
-            uint32_t* __restrict__ table)
+k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+                 KeyParams kp, uint64_t chunk, uint32_t* __restrict__ flags)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                 // NB
-    uint8_t* s_text = smem + (size_t)kp.nbins * 4;                       // TILE + HALO
-    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_text + TILE + HALO); // 256
-
-    const uint32_t mask = kp.nbins - 1;
-    for (uint32_t i = threadIdx.x; i < kp.nbins; i += THREADS) s_cnt[i] = 0;
+    uint8_t* s_flag = smem;                                              // raw_bins
+    uint8_t* s_tile = smem + kp.raw_bins;                                // TILE + HALO
+    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_tile + TILE + HALO);  // 256
+    for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS) s_flag[i] = 0;
     load_lut(glut, s_lut);
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();
-        stage_text_tile(text, tile0, s_text);
+        TileKeys tk;
+        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk);
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (tile0 + threadIdx.x * EPT + e < n) s_flag[(uint32_t)(tk.key[e] >> kp.top_shift)] = 1;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS)
+        if (s_flag[i]) flags[i] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hist_text: per-workgroup digit histogram of the first radix pass, streaming the text.
+// Row w of `table` (layout [workgroup][bin]) counts the digit of every eligible position of workgroup
+// w's text chunk whose TOP digit lies in [top_lo, top_hi) (the shard filter used when a genome is split
+// over GPUs by prefix-bucket range; top_lo/top_hi are dense digit values).
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__global__ void __launch_bounds__(THREADS)
+k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+            const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
+            uint32_t top_lo, uint32_t top_hi, uint32_t* __restrict__ table)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                  // nbins
+    uint8_t* s_tile = smem + (size_t)kp.nbins * 4;                        // TILE + HALO
+    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_tile + TILE + HALO);  // 256
+    uint16_t* s_rm = s_lut + 256;                                         // raw_bins
+
+    const uint32_t raw_mask = kp.raw_bins - 1;
+    for (uint32_t i = threadIdx.x; i < kp.nbins; i += THREADS) s_cnt[i] = 0;
+    load_lut(glut, s_lut);
+    const uint16_t* s_remap = load_remap(gremap, s_rm, kp.raw_bins);
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t c1 = min(c0 + chunk, n);
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();
         TileKeys tk;
-        build_tile_keys(s_text, s_lut, tile0, n, kp.b, kp.K, tk);
+        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk);
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             if (tk.elig & (1u << e)) {
-                uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift);
+                uint32_t top = digit_of(tk.key[e], kp.top_shift, raw_mask, s_remap);
                 if (top >= top_lo && top < top_hi)
-                    atomicAdd(&s_cnt[(uint32_t)(tk.key[e] >> shift) & mask], 1u);
+                    atomicAdd(&s_cnt[digit_of(tk.key[e], shift, raw_mask, s_remap)], 1u);
             }
         }
     }
@@ -204,9 +324,9 @@ k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Block-wide exclusive scan of s_cnt[0..nbins) (nbins % THREADS == 0 or nbins < THREADS).
-// On return s_cnt holds the exclusive prefix and *s_total the total.  Also applies the per-tile
-// bookkeeping of the scatter kernels:  gdelta[d] = gbase[d] - prefix[d];  gbase[d] += count[d].
+// Block-wide exclusive scan of s_cnt[0..nbins).  On return s_cnt holds the exclusive prefix and
+// *s_total the total.  Also applies the per-tile bookkeeping of the scatter kernels:
+//     gdelta[d] = gbase[d] - prefix[d];   gbase[d] += count[d].
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_scan_bins(uint32_t* s_cnt, uint32_t* s_gbase, uint32_t* s_gdelta,
                                                 uint32_t nbins, uint32_t* s_wsum, uint32_t* s_total)
@@ -218,7 +338,6 @@ __device__ __forceinline__ void block_scan_bins(uint32_t* s_cnt, uint32_t* s_gba
         uint32_t d = d0 + k;
         if (d < nbins) local += s_cnt[d];
     }
-    // inclusive scan of `local` across the 256 threads: wave scan + LDS
     uint32_t incl = local;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -254,46 +373,50 @@ __device__ __forceinline__ void block_scan_bins(uint32_t* s_cnt, uint32_t* s_gba
 // Algorithmic bytes: n (text) + 4 s (indices) [+ 8 s for the keys carried to later passes].
 // The first LSD pass has no earlier order to preserve, so ranking by LDS atomics is sufficient.
 // ---------------------------------------------------------------------------------------------
+template <int B>
 __global__ void __launch_bounds__(THREADS)
 k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
-               KeyParams kp, int shift, uint64_t chunk, uint32_t top_lo, uint32_t top_hi,
+               const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
+               uint32_t top_lo, uint32_t top_hi,
                const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
                uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t NB = kp.nbins;
+    const uint32_t NBa = (NB + 3u) & ~3u;                  // keep the arrays below 16-byte aligned
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);   // NB
-    uint32_t* s_gbase = s_cnt + NB;                        // NB
-    uint32_t* s_gdelta = s_gbase + NB;                     // NB
-    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NB);  // TILE
-    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);   // TILE
-    uint8_t* s_text = reinterpret_cast<uint8_t*>(s_idx + TILE);    // TILE + HALO
-    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_text + TILE + HALO);  // 256
-    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_lut + 256);   // 8
+    uint32_t* s_gbase = s_cnt + NBa;                       // NB
+    uint32_t* s_gdelta = s_gbase + NBa;                    // NB
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);  // TILE
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);    // TILE
+    uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_idx + TILE);     // TILE + HALO
+    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_tile + TILE + HALO);  // 256
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_lut + 256);    // 8
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 8);       // raw_bins
 
-    const uint32_t mask = NB - 1;
+    const uint32_t raw_mask = kp.raw_bins - 1;
     const uint32_t* row = table + (size_t)blockIdx.x * NB;
     for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_gbase[i] = row[i] + binbase[i];
     load_lut(glut, s_lut);
+    const uint16_t* s_remap = load_remap(gremap, s_rm, kp.raw_bins);
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_cnt[i] = 0;
-        stage_text_tile(text, tile0, s_text);
-        __syncthreads();
         TileKeys tk;
-        build_tile_keys(s_text, s_lut, tile0, n, kp.b, kp.K, tk);
-        uint32_t rank[EPT];
+        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk);   // contains the barrier after staging
+        uint32_t rank[EPT], dig[EPT];
         uint32_t keep = 0;
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
-            rank[e] = 0;
+            rank[e] = 0; dig[e] = 0;
             if (tk.elig & (1u << e)) {
-                uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift);
+                uint32_t top = digit_of(tk.key[e], kp.top_shift, raw_mask, s_remap);
                 if (top >= top_lo && top < top_hi) {
                     keep |= 1u << e;
-                    rank[e] = atomicAdd(&s_cnt[(uint32_t)(tk.key[e] >> shift) & mask], 1u);
+                    dig[e] = digit_of(tk.key[e], shift, raw_mask, s_remap);
+                    rank[e] = atomicAdd(&s_cnt[dig[e]], 1u);
                 }
             }
         }
@@ -303,8 +426,7 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             if (keep & (1u << e)) {
-                uint32_t d = (uint32_t)(tk.key[e] >> shift) & mask;
-                uint32_t pos = s_cnt[d] + rank[e];
+                uint32_t pos = s_cnt[dig[e]] + rank[e];
                 s_key[pos] = tk.key[e];
                 s_idx[pos] = (uint32_t)(tile0 + threadIdx.x * EPT + e);
             }
@@ -312,8 +434,7 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < total; j += THREADS) {
             uint64_t k = s_key[j];
-            uint32_t d = (uint32_t)(k >> shift) & mask;
-            uint32_t o = j + s_gdelta[d];
+            uint32_t o = j + s_gdelta[digit_of(k, shift, raw_mask, s_remap)];
             out_key[o] = k;
             out_idx[o] = s_idx[j];
         }
@@ -326,12 +447,15 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(THREADS)
 k_hist_pairs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ seg, uint32_t m,
-             uint32_t nbins, int shift, uint32_t chunk, uint32_t* __restrict__ table)
+             uint32_t nbins, uint32_t raw_bins, const uint16_t* __restrict__ gremap, int shift, uint32_t chunk,
+             uint32_t* __restrict__ table)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t mask = nbins - 1;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                // nbins
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_cnt + nbins);        // raw_bins
+    const uint32_t mask = raw_bins - 1;
     for (uint32_t i = threadIdx.x; i < nbins; i += THREADS) s_cnt[i] = 0;
+    const uint16_t* s_remap = load_remap(gremap, s_rm, raw_bins);
     __syncthreads();
     const uint32_t c0 = blockIdx.x * chunk;
     const uint32_t c1 = min(c0 + chunk, m);
@@ -340,7 +464,7 @@ k_hist_pairs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ seg
             atomicAdd(&s_cnt[(seg[j] >> shift) & mask], 1u);
     } else {
         for (uint32_t j = c0 + threadIdx.x; j < c1; j += THREADS)
-            atomicAdd(&s_cnt[(uint32_t)(keys[j] >> shift) & mask], 1u);
+            atomicAdd(&s_cnt[digit_of(keys[j], shift, mask, s_remap)], 1u);
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * nbins;
@@ -373,6 +497,7 @@ template <bool HAS_SEG>
 __global__ void __launch_bounds__(THREADS)
 k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict__ in_idx,
                 const uint32_t* __restrict__ in_seg, uint32_t m, uint32_t nbins, int nbits,
+                uint32_t raw_bins, const uint16_t* __restrict__ gremap,
                 int shift, int digit_from_seg, uint32_t chunk,
                 const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
                 uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx,
@@ -380,21 +505,24 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t NB = nbins;
+    const uint32_t NBa = (NB + 3u) & ~3u;
     constexpr int NW = THREADS / WAVE;
     uint32_t* s_gbase = reinterpret_cast<uint32_t*>(smem);  // NB
-    uint32_t* s_gdelta = s_gbase + NB;                      // NB
-    uint32_t* s_tot = s_gdelta + NB;                        // NB   tile count -> tile prefix
-    uint32_t* s_misc = s_tot + NB;                          // 8
-    uint8_t* s_union = reinterpret_cast<uint8_t*>(s_misc + 8);
+    uint32_t* s_gdelta = s_gbase + NBa;                     // NB
+    uint32_t* s_tot = s_gdelta + NBa;                       // NB   tile count -> tile prefix
+    uint32_t* s_misc = s_tot + NBa;                         // 8
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 8);           // raw_bins (if remapped)
+    uint8_t* s_union = reinterpret_cast<uint8_t*>(s_rm + (gremap ? ((raw_bins + 7u) & ~7u) : 0u));
     // union region: per-wave counters (NW*NB u16) during ranking, then the staging arrays
     uint16_t* s_wcnt = reinterpret_cast<uint16_t*>(s_union);
     uint64_t* s_key = reinterpret_cast<uint64_t*>(s_union);
     uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);
     uint32_t* s_seg = s_idx + TILE;
 
-    const uint32_t mask = NB - 1;
+    const uint32_t mask = raw_bins - 1;
     const uint32_t* row = table + (size_t)blockIdx.x * NB;
     for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_gbase[i] = row[i] + binbase[i];
+    const uint16_t* s_remap = load_remap(gremap, s_rm, raw_bins);
     const uint32_t c0 = blockIdx.x * chunk;
     const uint32_t c1 = min(c0 + chunk, m);
     const int wv = threadIdx.x >> 6;
@@ -403,7 +531,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
 
     for (uint32_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();  // previous tile's copy-out done before the union region is reused
-        for (uint32_t i = threadIdx.x; i < NW * NB / 2; i += THREADS)
+        for (uint32_t i = threadIdx.x; i < (NW * NB + 1) / 2; i += THREADS)
             reinterpret_cast<uint32_t*>(s_wcnt)[i] = 0;
         __syncthreads();
         uint64_t key[EPT];
@@ -426,7 +554,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             bool v = valid & (1u << e);
-            uint32_t d = (digit_from_seg ? (sg[e] >> shift) : (uint32_t)(key[e] >> shift)) & mask;
+            uint32_t d = digit_from_seg ? ((sg[e] >> shift) & mask) : digit_of(key[e], shift, mask, s_remap);
             dig[e] = d;
             uint64_t mm = match_digit(d, nbits, v);
             uint32_t before = 0;
@@ -471,7 +599,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
         for (uint32_t j = threadIdx.x; j < total; j += THREADS) {
             uint64_t k = s_key[j];
             uint32_t sgv = HAS_SEG ? s_seg[j] : 0u;
-            uint32_t d = (digit_from_seg ? (sgv >> shift) : (uint32_t)(k >> shift)) & mask;
+            uint32_t d = digit_from_seg ? ((sgv >> shift) & mask) : digit_of(k, shift, mask, s_remap);
             uint32_t o = j + s_gdelta[d];
             out_key[o] = k;
             out_idx[o] = s_idx[j];
@@ -678,16 +806,43 @@ __device__ __forceinline__ uint32_t run_key_advance(uint64_t key, int sorted_bit
     return t.rem + (plain > 0 ? (uint32_t)(plain / bits) : 0u);
 }
 
+// periodic extension length for period pi > 1: number of bytes from q on that equal the byte pi
+// positions earlier, capped at RUN_SAT (word-wise scan; tandem arrays are kilobases, not megabases)
+__device__ __forceinline__ uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint64_t q,
+                                                 uint32_t pi)
+{
+    uint32_t rem = 0;
+    while (rem < RUN_SAT && q + rem < n) {
+        uint64_t a = load_u64_unaligned(text + q + rem);
+        uint64_t b = load_u64_unaligned(text + q + rem - pi);
+        uint64_t x = a ^ b;
+        uint32_t same = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+        uint64_t room = n - (q + rem);
+        if (same > room) same = (uint32_t)room;
+        rem += same;
+        if (same < 8) break;
+    }
+    return rem < RUN_SAT ? rem : RUN_SAT;
+}
+
+// pi = period assumed for the group (1 = plain runs, served by the R array).  Any pi <= the length of the
+// group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
+// periodic extension up to the shorter of their two break points, and at the break the suffix whose text
+// leaves the extension is smaller iff its byte is below the byte the extension predicts there.
 __device__ __forceinline__ uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
                                                  const uint16_t* __restrict__ R, const uint16_t* s_lut,
-                                                 int bits, uint64_t q)
+                                                 int bits, uint64_t q, uint32_t pi)
 {
-    // q >= 1 and q <= n: the group shares at least one character
-    const uint32_t c = text[q - 1];
+    // q >= pi >= 1 and q <= n
     uint32_t rem = 0;
-    if (q < n && text[q] == c) rem = R[q];
+    if (pi == 1) {
+        if (q < n && text[q] == text[q - 1]) rem = R[q];
+    } else {
+        rem = periodic_rem(text, n, q, pi);
+    }
     const uint64_t after = q + rem;                    // <= n
     const uint32_t x = after < n ? (uint32_t)text[after] : 0u;
+    const uint32_t c = text[after - pi];               // what the periodic extension predicts at `after`
     const uint32_t cls = (after < n && x > c) ? 1u : 0u;
     const uint32_t v = rem + 1u;
     const int L = 31 - __clz(v);
@@ -895,11 +1050,11 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
         // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
         if (act0) {
             dd0 += plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b);
-            k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0);
+            k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u);
         }
         if (act1) {
             dd1 += plain ? (uint32_t)kp.K : run_key_advance(k1, 64, kp.b);
-            k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1);
+            k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u);
         }
         plain = false;
     }
@@ -924,15 +1079,15 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
 __global__ void __launch_bounds__(256)
 k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ R,
               const uint16_t* __restrict__ glut, const uint32_t* __restrict__ idx,
-              const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth, uint32_t m,
-              KeyParams kp, uint64_t* __restrict__ keys)
+              const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth,
+              const uint8_t* __restrict__ segperiod, uint32_t m, KeyParams kp, uint64_t* __restrict__ keys)
 {
     __shared__ uint16_t s_lut[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= m) return;
-    keys[e] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]]);
+    keys[e] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]]);
 }
 
 // size of every large group (upper bound of (segment, sorted bits) in the sorted records) and the depth
@@ -941,8 +1096,9 @@ template <bool DEEP>
 __global__ void __launch_bounds__(256)
 k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ segs,
                const uint32_t* __restrict__ segdepth, uint32_t m, int sorted_bits, KeyParams kp,
-               const uint32_t* __restrict__ heads, uint32_t L, uint32_t* __restrict__ sizes,
-               uint32_t* __restrict__ newdepth, uint32_t* __restrict__ maxsize)
+               const uint32_t* __restrict__ heads, const uint32_t* __restrict__ idxs,
+               const uint8_t* __restrict__ text, uint32_t L, uint32_t* __restrict__ sizes,
+               uint32_t* __restrict__ newdepth, uint8_t* __restrict__ newperiod, uint32_t* __restrict__ maxsize)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= L) return;
@@ -959,8 +1115,22 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
     }
     uint32_t sz = lo - h;
     sizes[k] = sz;
-    newdepth[k] = DEEP ? segdepth[sg] + run_key_advance(hk, sorted_bits, kp.b)
-                       : (uint32_t)(sorted_bits / kp.b);
+    const uint32_t nd = DEEP ? segdepth[sg] + run_key_advance(hk, sorted_bits, kp.b)
+                             : (uint32_t)(sorted_bits / kp.b);
+    newdepth[k] = nd;
+    // smallest period (1..8) of the last 16 characters of the group's common prefix, else 1:
+    // tandem arrays are then crossed in one step by the periodic run token of make_run_key
+    uint32_t pi = 1;
+    if (nd >= 12) {
+        const uint8_t* e = text + (uint64_t)idxs[h] + nd;    // one past the common prefix
+        const uint32_t win = nd < 16 ? nd : 16;
+        for (uint32_t c = 1; c <= 8 && c * 2 <= win; c++) {
+            bool ok = true;
+            for (uint32_t i = 1; i + c <= win && ok; i++) ok = e[-(int)i] == e[-(int)(i + c)];
+            if (ok) { pi = c; break; }
+        }
+    }
+    newperiod[k] = (uint8_t)pi;
     atomicMax(maxsize, sz);
 }
 
