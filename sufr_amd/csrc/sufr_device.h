@@ -19,6 +19,7 @@ struct KeyParams {
     uint32_t raw_bins; // 1 << dbits: nominal digit values
     uint32_t nbins;    // digit values after the dense remap (== raw_bins when there is no remap)
     int top_shift;  // 64 - dbits: the most significant digit (shard selector)
+    int detect_period; // deep levels: use periodic run tokens for groups whose common prefix is periodic
 };
 
 }  // namespace sufr

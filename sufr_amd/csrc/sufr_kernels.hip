@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "sufr_device.h"
+#include "sufr_runkey.h"
 
 namespace sufr {
 
@@ -28,6 +29,12 @@ static constexpr int WAVE = 64;
 // small helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Pointer to LDS that stays in the LDS address space: accesses compile to ds_read/ds_write, which one wave
+// issues and completes in order.  (A plain `volatile T*` to a __shared__ object becomes a generic pointer
+// and hipcc then emits FLAT instructions, whose LDS accesses are NOT ordered -- a cross-lane exchange
+// through them races.)
+#define SUFR_LDS_VOLATILE(T, p) ((__attribute__((address_space(3))) volatile T*)(p))
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
@@ -49,14 +56,6 @@ __device__ __forceinline__ uint64_t shfl64_up1(uint64_t v)
     lo = __shfl_up(lo, 1, WAVE);
     hi = __shfl_up(hi, 1, WAVE);
     return ((uint64_t)hi << 32) | lo;
-}
-
-// unaligned 8-byte little-endian load (the text buffer is padded with >= 64 zero bytes)
-__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p)
-{
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -149,28 +148,34 @@ __device__ __forceinline__ const uint16_t* load_remap(const uint16_t* __restrict
 // Each thread converts 16 raw bytes to code bytes (code | 0x80 if eligible, 0 past the end) and stores
 // them with one 16-byte LDS write; keys are then built from 16-byte LDS reads held in registers, so the
 // LDS sees no strided byte traffic.
+__device__ __forceinline__ uint4 encode16(uint4 w, uint64_t pos0, uint64_t n, const uint16_t* s_lut)
+{
+    uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t y = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t l = s_lut[(ws[k] >> (8 * j)) & 0xffu];
+            uint32_t c = (pos0 + k * 4 + j < n) ? ((l & 0x7fu) | ((l >> 8) & 0x80u)) : 0u;
+            y |= c << (8 * j);
+        }
+        ws[k] = y;
+    }
+    return make_uint4(ws[0], ws[1], ws[2], ws[3]);
+}
+
+// `mine` = the 16 raw bytes of this thread's own positions, loaded one tile ahead by the caller
 template <int B>
 __device__ __forceinline__ void stage_code_tile(const uint8_t* __restrict__ text, uint64_t tile0, uint64_t n,
-                                                const uint16_t* s_lut, uint8_t* s_code)
+                                                const uint16_t* s_lut, uint8_t* s_code, uint4 mine)
 {
-    const uint4* src = reinterpret_cast<const uint4*>(text + tile0);  // text is padded; tile0 % 16 == 0
     uint4* dst = reinterpret_cast<uint4*>(s_code);
-    for (int v = threadIdx.x; v < (TILE + HALO) / 16; v += THREADS) {
-        uint4 w = src[v];
-        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-        const uint64_t pos0 = tile0 + (uint64_t)v * 16;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t y = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t l = s_lut[(ws[k] >> (8 * j)) & 0xffu];
-                uint32_t c = (pos0 + k * 4 + j < n) ? ((l & 0x7fu) | ((l >> 8) & 0x80u)) : 0u;
-                y |= c << (8 * j);
-            }
-            ws[k] = y;
-        }
-        dst[v] = make_uint4(ws[0], ws[1], ws[2], ws[3]);
+    dst[threadIdx.x] = encode16(mine, tile0 + (uint64_t)threadIdx.x * 16, n, s_lut);
+    if (threadIdx.x < HALO / 16) {   // halo: the first bytes of the next tile (text is padded)
+        const int v = TILE / 16 + threadIdx.x;
+        uint4 w = reinterpret_cast<const uint4*>(text + tile0)[v];
+        dst[v] = encode16(w, tile0 + (uint64_t)v * 16, n, s_lut);
     }
 }
 
@@ -238,10 +243,10 @@ __device__ __forceinline__ void build_tile_keys(const uint8_t* s_text, const uin
 template <int B>
 __device__ __forceinline__ void tile_keys(const uint8_t* __restrict__ text, uint64_t tile0, uint64_t n,
                                           const uint16_t* s_lut, uint8_t* s_tile, const KeyParams& kp,
-                                          TileKeys& tk)
+                                          TileKeys& tk, uint4 mine)
 {
     if constexpr (B > 0) {
-        stage_code_tile<B>(text, tile0, n, s_lut, s_tile);
+        stage_code_tile<B>(text, tile0, n, s_lut, s_tile, mine);
         __syncthreads();
         build_tile_keys_fast<B>(s_tile, tk);
     } else {
@@ -268,10 +273,13 @@ k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
     load_lut(glut, s_lut);
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
+    uint4 nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();
+        const uint4 mine = nxt;
+        if (tile0 + TILE < c1) nxt = reinterpret_cast<const uint4*>(text + tile0 + TILE)[threadIdx.x];
         TileKeys tk;
-        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk);
+        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (tile0 + threadIdx.x * EPT + e < n) s_flag[(uint32_t)(tk.key[e] >> kp.top_shift)] = 1;
@@ -305,10 +313,13 @@ k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __rest
     const uint16_t* s_remap = load_remap(gremap, s_rm, kp.raw_bins);
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
+    uint4 nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();
+        const uint4 mine = nxt;
+        if (tile0 + TILE < c1) nxt = reinterpret_cast<const uint4*>(text + tile0 + TILE)[threadIdx.x];
         TileKeys tk;
-        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk);
+        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             if (tk.elig & (1u << e)) {
@@ -401,11 +412,14 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
     const uint16_t* s_remap = load_remap(gremap, s_rm, kp.raw_bins);
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
+    uint4 nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_cnt[i] = 0;
+        const uint4 mine = nxt;   // next tile's bytes are requested now and consumed one iteration later
+        if (tile0 + TILE < c1) nxt = reinterpret_cast<const uint4*>(text + tile0 + TILE)[threadIdx.x];
         TileKeys tk;
-        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk);   // contains the barrier after staging
+        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);   // contains the barrier after staging
         uint32_t rank[EPT], dig[EPT];
         uint32_t keep = 0;
 #pragma unroll
@@ -550,7 +564,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 key[e] = 0; idx[e] = 0; sg[e] = 0;
             }
         }
-        volatile uint16_t* my = s_wcnt + (size_t)wv * NB;
+        auto my = SUFR_LDS_VOLATILE(uint16_t, s_wcnt + (size_t)wv * NB);
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             bool v = valid & (1u << e);
@@ -678,7 +692,6 @@ k_scan_bins(const uint32_t* __restrict__ bintot, uint32_t nbins, uint32_t* __res
 //   k_run_first: per 4096-byte tile, position of the first run end (0xffffffff if the tile has none)
 //   k_run_fill:  R for every position, looking at most 16 tiles ahead (the saturation horizon)
 // ---------------------------------------------------------------------------------------------
-static constexpr uint32_t RUN_SAT = 65535u;
 
 __global__ void __launch_bounds__(256)
 k_run_first(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ first_end)
@@ -760,165 +773,43 @@ k_run_fill(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Run keys: the key format of every level below the first and of every tie round of the finisher.
-// All suffixes of a group agree on their first `q - idx` characters, in particular on c = text[q-1].
-// The key describes the text from q on as
-//     cls | gamma(rem + 1) [complemented if cls] | the characters after the run, b bits each
-//   rem = number of further bytes equal to c starting at q (0 if text[q] != c), saturating at 65535;
-//   x   = the byte after that run (end of text sorts lowest);   cls = (x > c).
-// Comparing  c^remA xA...  with  c^remB xB...:  if the runs differ in length, the shorter one is
-// smaller iff its x is below c -- so  {x < c, rem ascending} < {x > c, rem descending}; the Elias-gamma
-// code (L ones, a zero, L low bits) is order preserving and its complement reverses the order.
-// A saturated run has x == c, cls = 0 and continues with real text characters, which keeps the order.
-// The integer order of run keys therefore equals the suffix order, and a run of any length costs one
-// R lookup instead of a byte-by-byte walk.
-// ---------------------------------------------------------------------------------------------
-struct RunTok { uint32_t cls, rem; int tokbits; };
-
-__device__ __forceinline__ RunTok decode_run_token(uint64_t key)
-{
-    RunTok t;
-    t.cls = (uint32_t)(key >> 63);
-    uint64_t g = key << 1;
-    if (t.cls) g = ~g;
-    int L = g == ~0ull ? 63 : __clzll(~g);    // leading ones
-    if (L > 16) L = 16;                        // rem + 1 <= 65536
-    uint32_t low = L ? (uint32_t)((g << (L + 1)) >> (64 - L)) : 0u;
-    t.rem = ((1u << L) | low) - 1u;
-    t.tokbits = 2 + 2 * L;
-    return t;
-}
-
-// characters of common prefix described by two DIFFERENT keys of one group
-__device__ __forceinline__ uint32_t run_key_common(uint64_t a, uint64_t b, int bits)
-{
-    RunTok ta = decode_run_token(a), tb = decode_run_token(b);
-    if (ta.cls != tb.cls || ta.rem != tb.rem) return min(ta.rem, tb.rem);
-    uint64_t x = (a ^ b) << ta.tokbits;
-    return ta.rem + (x ? (uint32_t)(__clzll(x) / bits) : (uint32_t)((64 - ta.tokbits) / bits));
-}
-
-// characters covered by the top `sorted_bits` of a run key (what a group defined on them shares)
-__device__ __forceinline__ uint32_t run_key_advance(uint64_t key, int sorted_bits, int bits)
-{
-    RunTok t = decode_run_token(key);
-    int plain = sorted_bits - t.tokbits;
-    return t.rem + (plain > 0 ? (uint32_t)(plain / bits) : 0u);
-}
-
-// periodic extension length for period pi > 1: number of bytes from q on that equal the byte pi
-// positions earlier, capped at RUN_SAT (word-wise scan; tandem arrays are kilobases, not megabases)
-__device__ __forceinline__ uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint64_t q,
-                                                 uint32_t pi)
-{
-    uint32_t rem = 0;
-    while (rem < RUN_SAT && q + rem < n) {
-        uint64_t a = load_u64_unaligned(text + q + rem);
-        uint64_t b = load_u64_unaligned(text + q + rem - pi);
-        uint64_t x = a ^ b;
-        uint32_t same = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-        uint64_t room = n - (q + rem);
-        if (same > room) same = (uint32_t)room;
-        rem += same;
-        if (same < 8) break;
-    }
-    return rem < RUN_SAT ? rem : RUN_SAT;
-}
-
-// pi = period assumed for the group (1 = plain runs, served by the R array).  Any pi <= the length of the
-// group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
-// periodic extension up to the shorter of their two break points, and at the break the suffix whose text
-// leaves the extension is smaller iff its byte is below the byte the extension predicts there.
-__device__ __forceinline__ uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
-                                                 const uint16_t* __restrict__ R, const uint16_t* s_lut,
-                                                 int bits, uint64_t q, uint32_t pi)
-{
-    // q >= pi >= 1 and q <= n
-    uint32_t rem = 0;
-    if (pi == 1) {
-        if (q < n && text[q] == text[q - 1]) rem = R[q];
-    } else {
-        rem = periodic_rem(text, n, q, pi);
-    }
-    const uint64_t after = q + rem;                    // <= n
-    const uint32_t x = after < n ? (uint32_t)text[after] : 0u;
-    const uint32_t c = text[after - pi];               // what the periodic extension predicts at `after`
-    const uint32_t cls = (after < n && x > c) ? 1u : 0u;
-    const uint32_t v = rem + 1u;
-    const int L = 31 - __clz(v);
-    const int glen = 2 * L + 1;
-    uint64_t g = (((1ull << L) - 1ull) << (L + 1)) | (uint64_t)(v & ((1u << L) - 1u));
-    if (cls) g = ~g & ((1ull << glen) - 1ull);
-    const int tokbits = 1 + glen;
-    uint64_t key = ((uint64_t)cls << 63) | (g << (63 - glen));
-    int shift = 64 - tokbits;
-    const int nch = shift / bits;
-    int j = 0;
-    while (j < nch) {
-        uint64_t w = (after + j < n) ? load_u64_unaligned(text + after + j) : 0ull;
-        int lim = min(8, nch - j);
-        for (int t = 0; t < lim; t++) {
-            uint32_t code = (after + j + t < n) ? (uint32_t)(s_lut[(w >> (8 * t)) & 0xffu] & 0x3ffu) : 0u;
-            shift -= bits;
-            key |= (uint64_t)code << shift;
-        }
-        j += lim;
-    }
-    return key;
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_finish: wave-level finisher.  Input: records sorted by (segment, top `sorted_bits` of the key).
-// A *group* is a maximal run of records equal in (segment, those bits).  Wave t owns the groups whose
-// first record lies in slots [64t, 64t+64) and sees the 128-slot window [64t, 64t+128).
+// A *group* is a maximal run of records equal in (segment, those bits).  Wave t owns the window of
+// records [128t, 128t+128) and the groups whose first record lies in it.
 //   * groups that end inside the window ("small") are completely ordered here: round 0 ranks the
 //     members by their whole key; every further round re-keys the still-tied suffixes with a run key
 //     taken where their common prefix ends and ranks again, until every suffix is alone.  Ranking is a
 //     counting sort through wave-private LDS (rank = members that compare lower), cheap for the tiny
 //     groups that dominate; the LCP written at a split is depth + common characters of the two keys.
-//   * groups that run past the window ("large") are appended to `large_heads`; the next level re-keys
+//   * groups that run past the window's end ("large") are appended to `large_heads`; the next level re-keys
 //     them where their common prefix ends (k_group_extent / k_build_level / k_gather_keys).
 // The LCP at a group's first record is its key-derived LCP with the record before it (another group):
 // the boundary LCP the reference recomputes in write() (sufr_builder.rs:893-902).
 // Level 0 keys are plain packed characters (PLAIN0); deeper levels carry run keys.
 // ---------------------------------------------------------------------------------------------
-// inclusive max-scan over the 128 slots of (v0 @ slot lane, v1 @ slot 64+lane)
-__device__ __forceinline__ void maxscan128(int& v0, int& v1)
-{
-    const int ln = (int)lane_id();
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        int t0 = __shfl_up(v0, o, WAVE);
-        int t1 = __shfl_up(v1, o, WAVE);
-        if (ln >= o) { v0 = max(v0, t0); v1 = max(v1, t1); }
-    }
-    int last0 = __shfl(v0, 63, WAVE);
-    v1 = max(v1, last0);
-}
 
-// for each slot, the smallest value found at a slot strictly greater than it (else `sentinel`)
-__device__ __forceinline__ void next_min128(int h0, int h1, int sentinel, int& n0, int& n1)
+// Head bookkeeping on two 64-bit lane masks (slots 0..63 in M0, 64..127 in M1).
+// highest set slot <= `slot`, or -1
+__device__ __forceinline__ int mask_prev_set(uint64_t M0, uint64_t M1, int slot)
 {
-    const int ln = (int)lane_id();
-    int s0 = h0, s1 = h1;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        int t0 = __shfl_down(s0, o, WAVE);
-        int t1 = __shfl_down(s1, o, WAVE);
-        if (ln + o < WAVE) { s0 = min(s0, t0); s1 = min(s1, t1); }
+    if (slot >= 64) {
+        uint64_t m = M1 & (~0ull >> (127 - slot));
+        if (m) return 127 - __clzll(m);
+        return M0 ? 63 - __clzll(M0) : -1;
     }
-    int first1 = __shfl(s1, 0, WAVE);
-    s0 = min(s0, first1);
-    int e0 = __shfl_down(s0, 1, WAVE);
-    int e1 = __shfl_down(s1, 1, WAVE);
-    if (ln == 63) { e0 = first1; e1 = sentinel; }
-    n0 = min(e0, sentinel); n1 = min(e1, sentinel);
+    uint64_t m = M0 & (~0ull >> (63 - slot));
+    return m ? 63 - __clzll(m) : -1;
 }
-
-__device__ __forceinline__ uint32_t plain_key_common(uint64_t a, uint64_t b, int bits, int K)
+// lowest set slot > `slot`, or `none`
+__device__ __forceinline__ int mask_next_set(uint64_t M0, uint64_t M1, int slot, int none)
 {
-    uint64_t x = a ^ b;
-    return x ? (uint32_t)(__clzll(x) / bits) : (uint32_t)K;
+    if (slot < 64) {
+        uint64_t m = slot == 63 ? 0ull : (M0 & (~0ull << (slot + 1)));
+        if (m) return __builtin_ctzll(m);
+        return M1 ? 64 + __builtin_ctzll(M1) : none;
+    }
+    uint64_t m = slot == 127 ? 0ull : (M1 & (~0ull << (slot - 63)));
+    return m ? 64 + __builtin_ctzll(m) : none;
 }
 
 template <bool DEEP>
@@ -938,13 +829,15 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
 
+    // one wave per window of 128 consecutive records; a group that crosses the window's end is "large"
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const uint32_t base = wave * 64;
-    if (base >= m) return;
+    const uint64_t base64 = (uint64_t)wave * 128;
+    if (base64 >= m) return;
+    const uint32_t base = (uint32_t)base64;
     const int wv = threadIdx.x >> 6;
-    volatile uint64_t* sk = sh_key[wv];
-    volatile uint32_t* si = sh_idx[wv];
-    volatile uint32_t* sg = sh_gid[wv];
+    auto sk = SUFR_LDS_VOLATILE(uint64_t, sh_key[wv]);
+    auto si = SUFR_LDS_VOLATILE(uint32_t, sh_idx[wv]);
+    auto sg = SUFR_LDS_VOLATILE(uint32_t, sh_gid[wv]);
     const int ln = (int)lane_id();
     const int group_shift = 64 - sorted_bits;
     const uint32_t j0 = base + ln, j1 = base + 64 + ln;
@@ -954,14 +847,13 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     uint32_t i0 = in0 ? idxs[j0] : 0u, i1 = in1 ? idxs[j1] : 0u;
     uint32_t sg0 = 0, sg1 = 0;
     if (DEEP) { sg0 = in0 ? segs[j0] : 0xffffffffu; sg1 = in1 ? segs[j1] : 0xffffffffu; }
-    // depth at which this record's key was taken (per segment below level 0)
-    uint32_t dd0 = 0, dd1 = 0;
+    uint32_t dd0 = 0, dd1 = 0;       // depth at which the record's key was taken (per segment below level 0)
     if (DEEP) { dd0 = in0 ? segdepth[sg0] : 0u; dd1 = in1 ? segdepth[sg1] : 0u; }
 
     // record before the window (slot -1) and after it (slot 128)
     uint64_t kprev = 0, knext = 0; uint32_t sprev = 0, snext = 0;
     const bool has_prev = base > 0;
-    const bool has_next = (base + 128) < m;
+    const bool has_next = (base64 + 128) < m;
     if (has_prev) { kprev = keys[base - 1]; if (DEEP) sprev = segs[base - 1]; }
     if (has_next) { knext = keys[base + 128]; if (DEEP) snext = segs[base + 128]; }
 
@@ -976,6 +868,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     uint64_t last1k = shfl64(k1, 63); uint32_t last1s = __shfl(sg1, 63, WAVE);
     const bool h128 = !has_next || (DEEP && snext != last1s) ||
                       ((knext >> group_shift) != (last1k >> group_shift));
+    const uint64_t H0 = __ballot(h0), H1 = __ballot(h1);
 
     // first record of a segment (or of everything): its LCP belongs to the parent level / is 0
     const bool first0 = (ln == 0 && !has_prev) || segdiff0;
@@ -985,18 +878,22 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     if (!first0 && in0) lcp0 = dd0 + (DEEP ? run_key_common(p0, k0, kp.b) : plain_key_common(p0, k0, kp.b, kp.K));
     if (!first1 && in1) lcp1 = dd1 + (DEEP ? run_key_common(p1, k1, kp.b) : plain_key_common(p1, k1, kp.b, kp.K));
 
-    // ---- group ids: head slot of the group each slot belongs to -----------------------------------
-    int g0 = h0 ? ln : -1, g1 = h1 ? (64 + ln) : -1;
-    maxscan128(g0, g1);
-    int nx0, nx1;
-    next_min128(h0 ? ln : 1000, h1 ? (64 + ln) : 1000, h128 ? 128 : 1000, nx0, nx1);
-    const bool own0 = in0 && g0 >= 0 && g0 < 64, own1 = in1 && g1 >= 0 && g1 < 64;
+    // ---- groups: head slot of each slot's group, and the next head after it -----------------------
+    const int g0 = mask_prev_set(H0, H1, ln), g1 = mask_prev_set(H0, H1, 64 + ln);
+    const int none = h128 ? 128 : 1000;
+    const int nx0 = mask_next_set(H0, H1, ln, none), nx1 = mask_next_set(H0, H1, 64 + ln, none);
+    const bool own0 = in0 && g0 >= 0, own1 = in1 && g1 >= 0;       // group starts inside this window
     const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
     if (own0 && h0 && !small0) {            // a large group is reported once, by its head slot
         uint32_t at = atomicAdd(large_count, 1u);
         large_heads[at] = j0;
         if (!first0) LCP[DEEP ? opos[j0] : j0] = lcp0;
         else if (!DEEP) LCP[j0] = 0;
+    }
+    if (own1 && h1 && !small1) {
+        uint32_t at = atomicAdd(large_count, 1u);
+        large_heads[at] = j1;
+        if (!first1) LCP[DEEP ? opos[j1] : j1] = lcp1;
     }
     bool act0 = small0 && !(h0 && nx0 == ln + 1);     // member of a small group with > 1 records
     bool act1 = small1 && !(h1 && nx1 == 64 + ln + 1);
@@ -1038,11 +935,11 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
         const bool tie0 = same0 && q0 == k0, tie1 = same1 && q1 == k1;
         if (same0 && !tie0) lcp0 = dd0 + (plain ? plain_key_common(q0, k0, kp.b, kp.K) : run_key_common(q0, k0, kp.b));
         if (same1 && !tie1) lcp1 = dd1 + (plain ? plain_key_common(q1, k1, kp.b, kp.K) : run_key_common(q1, k1, kp.b));
-        int ng0 = tie0 ? -1 : ln, ng1 = tie1 ? -1 : (64 + ln);
-        maxscan128(ng0, ng1);
-        bool s0n = __shfl_down((int)tie0, 1, WAVE), s1n = __shfl_down((int)tie1, 1, WAVE);
-        bool f1 = __shfl((int)tie1, 0, WAVE);
-        if (ln == 63) { s0n = f1; s1n = false; }
+        const uint64_t T0 = __ballot(tie0), T1 = __ballot(tie1);
+        // new group of a slot = nearest slot at or before it that does not tie with its predecessor
+        const int ng0 = mask_prev_set(~T0, ~T1, ln), ng1 = mask_prev_set(~T0, ~T1, 64 + ln);
+        const bool s0n = ln < 63 ? ((T0 >> (ln + 1)) & 1ull) : (T1 & 1ull);   // my successor ties with me
+        const bool s1n = ln < 63 ? ((T1 >> (ln + 1)) & 1ull) : false;
         act0 = act0 && (tie0 || s0n);
         act1 = act1 && (tie1 || s1n);
         gid0 = act0 ? (uint32_t)ng0 : (0x10000u | (uint32_t)ln);
@@ -1121,7 +1018,7 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
     // smallest period (1..8) of the last 16 characters of the group's common prefix, else 1:
     // tandem arrays are then crossed in one step by the periodic run token of make_run_key
     uint32_t pi = 1;
-    if (nd >= 12) {
+    if (nd >= 12 && kp.detect_period) {
         const uint8_t* e = text + (uint64_t)idxs[h] + nd;    // one past the common prefix
         const uint32_t win = nd < 16 ? nd : 16;
         for (uint32_t c = 1; c <= 8 && c * 2 <= win; c++) {

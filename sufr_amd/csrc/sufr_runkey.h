@@ -1,0 +1,144 @@
+// sufr_runkey.h -- key formats shared by the device kernels and the host-side unit tests.
+// Everything here is plain integer code on a padded text; SUFR_HD makes it callable from both sides.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define SUFR_HD __host__ __device__ __forceinline__
+#else
+#define SUFR_HD static inline
+#endif
+
+namespace sufr {
+
+static constexpr uint32_t RUN_SAT = 65535u;   // saturation of the run-length array R
+
+// unaligned 8-byte little-endian load (the text buffer is padded with >= 64 zero bytes)
+SUFR_HD uint64_t load_u64_unaligned(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// common leading characters of two plain packed keys (K characters of `bits` bits from the top)
+SUFR_HD uint32_t plain_key_common(uint64_t a, uint64_t b, int bits, int K)
+{
+    uint64_t x = a ^ b;
+    return x ? (uint32_t)(__builtin_clzll(x) / bits) : (uint32_t)K;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Run keys: the key format of every level below the first and of every tie round of the finisher.
+// All suffixes of a group agree on their first `q - idx` characters, in particular on c = text[q-1].
+// The key describes the text from q on as
+//     cls | gamma(rem + 1) [complemented if cls] | the characters after the run, b bits each
+//   rem = number of further bytes equal to c starting at q (0 if text[q] != c), saturating at 65535;
+//   x   = the byte after that run (end of text sorts lowest);   cls = (x > c).
+// Comparing  c^remA xA...  with  c^remB xB...:  if the runs differ in length, the shorter one is
+// smaller iff its x is below c -- so  {x < c, rem ascending} < {x > c, rem descending}; the Elias-gamma
+// code (L ones, a zero, L low bits) is order preserving and its complement reverses the order.
+// A saturated run has x == c, cls = 0 and continues with real text characters, which keeps the order.
+// The integer order of run keys therefore equals the suffix order, and a run of any length costs one
+// R lookup instead of a byte-by-byte walk.
+// ---------------------------------------------------------------------------------------------
+struct RunTok { uint32_t cls, rem; int tokbits; };
+
+SUFR_HD RunTok decode_run_token(uint64_t key)
+{
+    RunTok t;
+    t.cls = (uint32_t)(key >> 63);
+    uint64_t g = key << 1;
+    if (t.cls) g = ~g;
+    int L = g == ~0ull ? 63 : __builtin_clzll(~g);    // leading ones
+    if (L > 16) L = 16;                        // rem + 1 <= 65536
+    uint32_t low = L ? (uint32_t)((g << (L + 1)) >> (64 - L)) : 0u;
+    t.rem = ((1u << L) | low) - 1u;
+    t.tokbits = 2 + 2 * L;
+    return t;
+}
+
+// characters of common prefix described by two DIFFERENT keys of one group
+SUFR_HD uint32_t run_key_common(uint64_t a, uint64_t b, int bits)
+{
+    RunTok ta = decode_run_token(a), tb = decode_run_token(b);
+    if (ta.cls != tb.cls || ta.rem != tb.rem) return (ta.rem < tb.rem ? ta.rem : tb.rem);
+    uint64_t x = (a ^ b) << ta.tokbits;
+    return ta.rem + (x ? (uint32_t)(__builtin_clzll(x) / bits) : (uint32_t)((64 - ta.tokbits) / bits));
+}
+
+// characters covered by the top `sorted_bits` of a run key (what a group defined on them shares)
+SUFR_HD uint32_t run_key_advance(uint64_t key, int sorted_bits, int bits)
+{
+    RunTok t = decode_run_token(key);
+    int plain = sorted_bits - t.tokbits;
+    return t.rem + (plain > 0 ? (uint32_t)(plain / bits) : 0u);
+}
+
+// periodic extension length for period pi > 1: number of bytes from q on that equal the byte pi
+// positions earlier, capped at RUN_SAT (word-wise scan; tandem arrays are kilobases, not megabases)
+SUFR_HD uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint64_t q,
+                                                 uint32_t pi)
+{
+    uint32_t rem = 0;
+    while (rem < RUN_SAT && q + rem < n) {
+        uint64_t a = load_u64_unaligned(text + q + rem);
+        uint64_t b = load_u64_unaligned(text + q + rem - pi);
+        uint64_t x = a ^ b;
+        uint32_t same = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+        uint64_t room = n - (q + rem);
+        if (same > room) same = (uint32_t)room;
+        rem += same;
+        if (same < 8) break;
+    }
+    return rem < RUN_SAT ? rem : RUN_SAT;
+}
+
+// pi = period assumed for the group (1 = plain runs, served by the R array).  Any pi <= the length of the
+// group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
+// periodic extension up to the shorter of their two break points, and at the break the suffix whose text
+// leaves the extension is smaller iff its byte is below the byte the extension predicts there.
+SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
+                                                 const uint16_t* __restrict__ R, const uint16_t* s_lut,
+                                                 int bits, uint64_t q, uint32_t pi)
+{
+    // q >= pi >= 1 and q <= n.  Loads are issued unconditionally (text and R are padded) so that the two
+    // dependent rounds of memory traffic -- {c, text[q], R[q]} then {x, prediction, following words} --
+    // each go out together instead of one load per branch.
+    uint32_t rem = 0;
+    if (pi == 1) {
+        const uint32_t cprev = text[q - 1], cq = text[q], r = R[q];
+        rem = (q < n && cq == cprev) ? r : 0u;
+    } else {
+        rem = periodic_rem(text, n, q, pi);
+    }
+    const uint64_t after = q + rem;                    // <= n
+    const uint8_t* ta = text + after;
+    const uint32_t x = ta[0];
+    const uint32_t c = ta[-(int)pi];                   // what the periodic extension predicts at `after`
+    uint64_t w0 = load_u64_unaligned(ta), w1 = load_u64_unaligned(ta + 8);
+    uint64_t w2 = load_u64_unaligned(ta + 16), w3 = load_u64_unaligned(ta + 24);
+    const uint32_t cls = (after < n && x > c) ? 1u : 0u;
+    const uint32_t v = rem + 1u;
+    const int L = 31 - __builtin_clz(v);
+    const int glen = 2 * L + 1;
+    uint64_t g = (((1ull << L) - 1ull) << (L + 1)) | (uint64_t)(v & ((1u << L) - 1u));
+    if (cls) g = ~g & ((1ull << glen) - 1ull);
+    const int tokbits = 1 + glen;
+    uint64_t key = ((uint64_t)cls << 63) | (g << (63 - glen));
+    int shift = 64 - tokbits;
+    const int nch = shift / bits;
+    const uint64_t room = n - after;                   // characters that exist from `after` on
+    const int live = room < (uint64_t)nch ? (int)room : nch;
+    for (int j = 0; j < live; j++) {
+        uint64_t w = j < 8 ? w0 : (j < 16 ? w1 : (j < 24 ? w2 : (j < 32 ? w3 : load_u64_unaligned(ta + (j & ~7)))));
+        uint32_t code = (uint32_t)(s_lut[(w >> (8 * (j & 7))) & 0xffu] & 0x3ffu);
+        shift -= bits;
+        key |= (uint64_t)code << shift;
+    }
+    return key;
+}
+
+
+}  // namespace sufr

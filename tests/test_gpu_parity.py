@@ -122,13 +122,21 @@ def test_empty_text(ctx):
     assert b.num_suffixes == 0
 
 
-def _break_long_n_runs(raw: np.ndarray) -> np.ndarray:
-    """Keep every N run shorter than 1000: the reference's N-run shortcut (sufr_builder.rs:302-307, only
-    active with allow_ambiguity) makes its own output approximate and merge-order dependent once two runs
-    of >= 1000 N exist, so bit-exact comparison with it is only meaningful below that length."""
+def _break_long_n_runs(raw: np.ndarray, soft: bool = False) -> np.ndarray:
+    """Keep every N run of the NORMALISED text shorter than 1000: the reference's N-run shortcut
+    (sufr_builder.rs:302-307, only active with allow_ambiguity) makes its own output approximate and
+    merge-order dependent (hence thread-schedule dependent) once runs of >= 1000 N exist, so bit-exact
+    comparison with it is only meaningful below that length.  With ignore_softmask, lowercase counts as N."""
     raw = raw.copy()
-    npos = np.nonzero((raw == ord("N")) | (raw == ord("n")))[0]
-    raw[npos[::500]] = ord("C")
+    isn = (raw == ord("N")) | (raw == ord("n"))
+    if soft:
+        isn |= (raw >= 97) & (raw <= 122)
+    pos = np.nonzero(isn)[0]
+    if pos.size:
+        new_run = np.concatenate([[True], np.diff(pos) != 1])
+        run_start = np.maximum.accumulate(np.where(new_run, np.arange(pos.size), 0))
+        within = np.arange(pos.size) - run_start
+        raw[pos[within % 500 == 499]] = ord("C")
     return raw
 
 
@@ -138,10 +146,7 @@ def test_softmask_ambiguity_delimiters(ctx, oracle, soft, amb):
     x, starts = synth.syn_human(400_000, seed=11)
     raw = x.numpy()
     if amb:
-        raw = _break_long_n_runs(raw)
-        if soft:   # lowercase becomes N as well: keep those runs short too
-            low = np.nonzero((raw >= 97) & (raw <= 122))[0]
-            raw[low[::400]] &= 0xDF
+        raw = _break_long_n_runs(raw, soft)
     assert_matches_oracle(ctx, oracle, raw, ignore_softmask=soft, allow_ambiguity=amb)
 
 
@@ -182,6 +187,19 @@ def test_long_repeats_need_deeper_levels(ctx, oracle):
     raw = np.concatenate([body, np.frombuffer(b"$", dtype=np.uint8)])
     b = assert_matches_oracle(ctx, oracle, raw)
     assert b.stats.num_levels > 1 and b.lcp.max() > 2000
+
+
+def test_many_near_identical_copies(ctx, oracle):
+    """40 copies of ten 1.5-4 kb families at 1 % divergence: tie groups of ~40 suffixes that split a few
+    members at a time over dozens of finisher rounds and across window borders (regression test for an
+    LDS-ordering race in the wave-private exchange)."""
+    g = synth._gen("cpu", 5)
+    text = synth._bases(g, 1_500_000, 0.645, "cpu")
+    for f in range(10):
+        synth._plant_family(g, text, synth._bases(g, 1500 + f * 300, 0.645, "cpu"), 40, 0.01, 0.01, lowercase=False)
+    x, _ = synth._join(text, 3)
+    for _ in range(2):
+        assert_matches_oracle(ctx, oracle, x.numpy())
 
 
 def test_protein_alphabet(ctx, oracle):
