@@ -116,10 +116,27 @@ def main():
     builder = sufr_amd.DeviceBuilder(local_rank)
     out_sa = out_lcp = None
     stats_acc = []
+    from sufr_amd import shards
+    soft = flags.get("ignore_softmask", False)
+    totals = {"s_total": 0}
+
     def step():
         nonlocal out_sa, out_lcp
         sa, lcp = builder.sort(text, raw_text=True, shard_index=rank, num_shards=world, out_sa=out_sa,
                                out_lcp=out_lcp, num_partitions=partitions, **flags)
+        s_local = builder.num_suffixes
+        if world > 1:
+            # the only exchange of the path: {first, last, count} per rank, then the boundary-LCP stitch
+            first = int(sa[0].item()) & 0xFFFFFFFF if s_local else 0
+            last = int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0
+            bounds = shards.exchange_boundaries(first, last, s_local, dev, dist)
+            k = shards.stitched_first_lcp(
+                bounds, rank, lambda st, ln: sufr_amd.normalize(text[st:st + ln].cpu().numpy(), soft), n)
+            if k is not None:
+                lcp[0] = k
+            totals["s_total"] = sum(b[2] for b in bounds)
+        else:
+            totals["s_total"] = s_local
         return sa, lcp
 
     # size the output arrays once (first call allocates n entries; later calls reuse them)
@@ -150,29 +167,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- boundary-LCP stitch across shards (the only exchange of the path) -------------------------
-    s_local = builder.num_suffixes
-    s_total = s_local
-    if world > 1:
-        mine = torch.tensor([int(sa[0].item()) & 0xFFFFFFFF if s_local else 0,
-                             int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0, s_local],
-                            dtype=torch.int64, device=dev)
-        allv = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        counts = [int(v[2].item()) for v in allv]
-        s_total = sum(counts)
-        prev = [r for r in range(rank) if counts[r] > 0]
-        if prev and s_local:
-            a = int(allv[prev[-1]][1].item()); b = int(allv[rank][0].item())
-            # exact LCP of the two boundary suffixes on the normalised text (few characters: they differ
-            # inside the first radix digit)
-            ta = text[a:a + 64].cpu().numpy(); tb = text[b:b + 64].cpu().numpy()
-            na = sufr_amd.normalize(ta, flags.get("ignore_softmask", False)); nb_ = sufr_amd.normalize(tb, flags.get("ignore_softmask", False))
-            k = 0
-            while k < min(na.size, nb_.size) and na[k] == nb_[k]:
-                k += 1
-            lcp[0] = k
-
+    s_total = totals["s_total"]
     if args.verify:
         sys.path.insert(0, str(ROOT / "tests"))
         from oracle_helper import check_sa_lcp_properties

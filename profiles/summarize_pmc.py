@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 --pmc counter_collection.csv files to one row per (sufr kernel, counter):
+the value of the LARGEST dispatch of that kernel (the top-level launch over the whole genome) and the mean
+over all its dispatches."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+out, dirs = sys.argv[1], sys.argv[2:]
+best = {}
+acc = defaultdict(lambda: [0.0, 0])
+for d in dirs:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"]
+            if "sufr::" not in name:
+                continue
+            short = name.split("(")[0].replace("void ", "")
+            key = (short, r["Counter_Name"])
+            v = float(r["Counter_Value"]); g = int(r["Grid_Size"])
+            a = acc[key]; a[0] += v; a[1] += 1
+            if key not in best or g > best[key][0]:
+                best[key] = (g, v)
+with open(out, "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "counter", "largest_dispatch_grid", "largest_dispatch_value", "mean_value", "dispatches"])
+    for key in sorted(best):
+        g, v = best[key]; s, c = acc[key]
+        w.writerow([key[0], key[1], g, v, s / c, c])
+print("wrote", out, len(best), "rows")

@@ -1,0 +1,56 @@
+"""Prefix-bucket shards across GPUs: the boundary exchange and LCP stitch.
+
+A genome sharded over N ranks (sufr_hip_sort_device_u32 with shard_index / num_shards) needs exactly one
+exchange: every rank publishes {first suffix, last suffix, count} (24 bytes) so that rank r can compute
+the LCP of its first suffix with the last suffix of the nearest non-empty shard before it -- the same
+boundary fix SufrBuilder::write applies between partitions (sufr_builder.rs:893-902) -- and knows its
+output offset (sum of the earlier counts).  `dist` is torch.distributed (backend nccl = RCCL on GPUs,
+gloo in the CPU tests)."""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+Boundary = Tuple[int, int, int]   # (first suffix, last suffix, count)
+
+
+def exchange_boundaries(first: int, last: int, count: int, device, dist=None) -> List[Boundary]:
+    """all_gather of one (first, last, count) triple per rank; returns the list indexed by rank."""
+    mine = torch.tensor([first, last, count], dtype=torch.int64, device=device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [tuple(int(v) for v in mine.tolist())]
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [tuple(int(v) for v in t.tolist()) for t in out]
+
+
+def output_offset(boundaries: List[Boundary], rank: int) -> int:
+    """Position of this shard's first entry in the concatenated SA / LCP arrays."""
+    return sum(b[2] for b in boundaries[:rank])
+
+
+def stitched_first_lcp(boundaries: List[Boundary], rank: int,
+                       norm_slice: Callable[[int, int], np.ndarray], text_len: int) -> Optional[int]:
+    """LCP of this shard's first suffix with the last suffix of the previous non-empty shard
+    (None for the globally first suffix, whose LCP is 0 by definition, and for empty shards).
+    norm_slice(start, length) returns normalised text bytes."""
+    if boundaries[rank][2] == 0:
+        return None
+    prev = [r for r in range(rank) if boundaries[r][2] > 0]
+    if not prev:
+        return None
+    a, b = boundaries[prev[-1]][1], boundaries[rank][0]
+    k, step = 0, 64
+    while True:
+        la = min(step, text_len - a - k); lb = min(step, text_len - b - k)
+        m = min(la, lb)
+        if m <= 0:
+            return k
+        x = norm_slice(a + k, m); y = norm_slice(b + k, m)
+        neq = np.nonzero(x != y)[0]
+        if neq.size:
+            return k + int(neq[0])
+        k += m
+        step = min(step * 4, 1 << 20)
