@@ -8,7 +8,7 @@ static constexpr int THREADS = 256;          // workgroup size of the radix kern
 static constexpr int EPT = 16;               // records / text positions per thread and tile
 static constexpr int TILE = THREADS * EPT;   // 4096
 static constexpr int HALO = 128;             // >= max K (64); text tile over-read for the rolling key
-static constexpr int TEXT_PAD = TILE + HALO + 64;  // zero bytes after the text in the workspace copy
+static constexpr int TEXT_PAD = 2 * TILE + HALO + 64;  // the largest scatter tile is 8192  // zero bytes after the text in the workspace copy
 
 // Key layout for one build (derived from the byte histogram of the normalised text).
 struct KeyParams {
@@ -19,6 +19,7 @@ struct KeyParams {
     uint32_t raw_bins; // 1 << dbits: nominal digit values
     uint32_t nbins;    // digit values after the dense remap (== raw_bins when there is no remap)
     int top_shift;  // 64 - dbits: the most significant digit (shard selector)
+    const uint8_t* packed; // text as a big-endian stream of b-bit codes (b <= 4), or nullptr
     int detect_period; // deep levels: use periodic run tokens for groups whose common prefix is periodic
 };
 

@@ -257,6 +257,41 @@ __device__ __forceinline__ void tile_keys(const uint8_t* __restrict__ text, uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_pack_codes: the text as a big-endian stream of B-bit codes (B <= 4: 16 codes fit one 64-bit word),
+// zero past the end.  Run keys then fetch "the next ~20 characters" with one unaligned 9-byte read
+// (make_run_key) instead of a per-character loop; 3/8 byte per base for DNA.
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__global__ void __launch_bounds__(256)
+k_pack_codes(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+             uint8_t* __restrict__ packed)
+{
+    __shared__ uint16_t s_lut[256];
+    __shared__ __align__(16) uint16_t s_pack[256 * B];
+    s_lut[threadIdx.x] = glut[threadIdx.x];
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
+    uint4 w = *reinterpret_cast<const uint4*>(text + p0);     // text is padded
+    uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    uint64_t V = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t byte = (ws[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        uint64_t c = (p0 + j < n) ? (uint64_t)(s_lut[byte] & 0x7fu) : 0ull;
+        V = (V << B) | c;
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        uint32_t h = (uint32_t)(V >> (16 * (B - 1 - k))) & 0xffffu;
+        s_pack[threadIdx.x * B + k] = (uint16_t)((h >> 8) | (h << 8));   // big-endian byte order
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(packed + (uint64_t)blockIdx.x * (TILE * B / 8));
+    const uint4* src = reinterpret_cast<const uint4*>(s_pack);
+    for (int v = threadIdx.x; v < TILE * B / 8 / 16; v += 256) dst[v] = src[v];
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_digit_presence: which dchars-mers (top-digit values of the key of EVERY text position) occur.
 // flags[v] = 1 for every value seen; the host turns the flags into the dense `remap`.
 // ---------------------------------------------------------------------------------------------
@@ -377,6 +412,102 @@ __device__ __forceinline__ void block_scan_bins(uint32_t* s_cnt, uint32_t* s_gba
 }
 
 // ---------------------------------------------------------------------------------------------
+// Geometry-generic helpers for the scatter kernels: NT threads per workgroup, E records (or text
+// positions) per thread, tile = NT * E.  (The histogram kernels keep 256 x 16; only the workgroup -> chunk
+// mapping has to agree, and chunks are multiples of every tile size.)
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void block_scan_bins_t(uint32_t* s_cnt, uint32_t* s_gbase, uint32_t* s_gdelta,
+                                                  uint32_t nbins, uint32_t* s_wsum, uint32_t* s_total)
+{
+    const uint32_t per = (nbins + NT - 1) / NT;  // bins per thread (consecutive)
+    const uint32_t d0 = threadIdx.x * per;
+    uint32_t local = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t d = d0 + k;
+        if (d < nbins) local += s_cnt[d];
+    }
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, WAVE);
+        if ((int)lane_id() >= o) incl += t;
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += s_wsum[w];
+    if (threadIdx.x == NT - 1) *s_total = wbase + incl;
+    uint32_t run = wbase + incl - local;
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t d = d0 + k;
+        if (d < nbins) {
+            uint32_t c = s_cnt[d];
+            s_cnt[d] = run;
+            uint32_t g = s_gbase[d];
+            s_gdelta[d] = g - run;
+            s_gbase[d] = g + c;
+            run += c;
+        }
+    }
+    __syncthreads();
+}
+
+template <int B, int E>
+__device__ __forceinline__ void build_keys_t(const uint8_t* s_code, uint64_t (&key)[E], uint32_t& elig)
+{
+    constexpr int K = 64 / B;
+    constexpr int NW8 = (E + K + 7) / 8;      // 8-byte words covering this thread's E + K code bytes
+    constexpr int low = 64 - K * B;
+    uint32_t w[NW8 * 2];
+    const uint2* src = reinterpret_cast<const uint2*>(s_code + threadIdx.x * E);   // E % 8 == 0
+#pragma unroll
+    for (int v = 0; v < NW8; v++) {
+        uint2 q = src[v];
+        w[2 * v] = q.x; w[2 * v + 1] = q.y;
+    }
+    uint64_t k = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) k = (k << B) | (uint64_t)((w[j >> 2] >> (8 * (j & 3))) & 0x7fu);
+    k <<= low;
+    elig = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        key[e] = k;
+        if ((w[e >> 2] >> (8 * (e & 3))) & 0x80u) elig |= 1u << e;
+        uint64_t c = (w[(e + K) >> 2] >> (8 * ((e + K) & 3))) & 0x7fu;
+        k = (k << B) | (c << low);
+    }
+}
+
+// generic-alphabet variant: raw bytes staged, per-byte lookups
+template <int E>
+__device__ __forceinline__ void build_keys_generic_t(const uint8_t* s_text, const uint16_t* s_lut, uint64_t tile0,
+                                                     uint64_t n, int b, int K, uint64_t (&key)[E], uint32_t& elig)
+{
+    const int p0 = threadIdx.x * E;
+    const int low = 64 - K * b;
+    uint64_t k = 0;
+    for (int j = 0; j < K; j++) {
+        uint64_t pos = tile0 + p0 + j;
+        uint32_t c = pos < n ? (uint32_t)(s_lut[s_text[p0 + j]] & 0x3ffu) : 0u;
+        k = (k << b) | c;
+    }
+    k <<= low;
+    elig = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        uint64_t pos = tile0 + p0 + e;
+        key[e] = k;
+        if (pos < n && (s_lut[s_text[p0 + e]] & 0x8000u)) elig |= 1u << e;
+        uint64_t nx = pos + K;
+        uint32_t c = nx < n ? (uint32_t)(s_lut[s_text[p0 + e + K]] & 0x3ffu) : 0u;
+        k = (k << b) | ((uint64_t)c << low);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_scatter_text: THE radix-partition kernel (first pass; suffix indices are implicit).
 // Streams the text once (coalesced 16 B / lane), builds the packed key of every eligible suffix,
 // ranks the tile's elements per digit with LDS counters, stages (key, idx) in LDS in digit order and
@@ -384,69 +515,87 @@ __device__ __forceinline__ void block_scan_bins(uint32_t* s_cnt, uint32_t* s_gba
 // Algorithmic bytes: n (text) + 4 s (indices) [+ 8 s for the keys carried to later passes].
 // The first LSD pass has no earlier order to preserve, so ranking by LDS atomics is sufficient.
 // ---------------------------------------------------------------------------------------------
-template <int B>
-__global__ void __launch_bounds__(THREADS)
+template <int B, int NT, int E, bool SHARDED>
+__global__ void __launch_bounds__(NT)
 k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
                const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
                uint32_t top_lo, uint32_t top_hi,
                const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
                uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx)
 {
+    constexpr int TILEB = NT * E;
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t NB = kp.nbins;
     const uint32_t NBa = (NB + 3u) & ~3u;                  // keep the arrays below 16-byte aligned
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);   // NB
     uint32_t* s_gbase = s_cnt + NBa;                       // NB
     uint32_t* s_gdelta = s_gbase + NBa;                    // NB
-    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);  // TILE
-    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);    // TILE
-    uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_idx + TILE);     // TILE + HALO
-    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_tile + TILE + HALO);  // 256
-    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_lut + 256);    // 8
-    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 8);       // raw_bins
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);   // TILEB
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILEB);    // TILEB
+    uint8_t* s_tile = reinterpret_cast<uint8_t*>(s_idx + TILEB);     // TILEB + HALO
+    uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_tile + TILEB + HALO);  // 256
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_lut + 256);     // 32
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 32);       // raw_bins
 
     const uint32_t raw_mask = kp.raw_bins - 1;
     const uint32_t* row = table + (size_t)blockIdx.x * NB;
-    for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_gbase[i] = row[i] + binbase[i];
-    load_lut(glut, s_lut);
-    const uint16_t* s_remap = load_remap(gremap, s_rm, kp.raw_bins);
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
+    for (int i = threadIdx.x; i < 256; i += NT) s_lut[i] = glut[i];
+    const uint16_t* s_remap = nullptr;
+    if (gremap) {
+        for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += NT) s_rm[i] = gremap[i];
+        s_remap = s_rm;
+    }
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
-    uint4 nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
-    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_cnt[i] = 0;
-        const uint4 mine = nxt;   // next tile's bytes are requested now and consumed one iteration later
-        if (tile0 + TILE < c1) nxt = reinterpret_cast<const uint4*>(text + tile0 + TILE)[threadIdx.x];
-        TileKeys tk;
-        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);   // contains the barrier after staging
-        uint32_t rank[EPT], dig[EPT];
+        for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
+        // stage the tile (+ halo): raw bytes -> code bytes, one 16-byte LDS store per 16 positions
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(text + tile0);
+            uint4* dst = reinterpret_cast<uint4*>(s_tile);
+            for (int v = threadIdx.x; v < (TILEB + HALO) / 16; v += NT) {
+                if constexpr (B > 0) dst[v] = encode16(src[v], tile0 + (uint64_t)v * 16, n, s_lut);
+                else dst[v] = src[v];
+            }
+        }
+        __syncthreads();
+        uint64_t key[E];
+        uint32_t elig;
+        if constexpr (B > 0) build_keys_t<B, E>(s_tile, key, elig);
+        else build_keys_generic_t<E>(s_tile, s_lut, tile0, n, kp.b, kp.K, key, elig);
+        uint32_t rank[E], dig[E];
         uint32_t keep = 0;
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
+        for (int e = 0; e < E; e++) {
             rank[e] = 0; dig[e] = 0;
-            if (tk.elig & (1u << e)) {
-                uint32_t top = digit_of(tk.key[e], kp.top_shift, raw_mask, s_remap);
-                if (top >= top_lo && top < top_hi) {
+            if (elig & (1u << e)) {
+                bool mine = true;
+                if constexpr (SHARDED) {
+                    uint32_t top = digit_of(key[e], kp.top_shift, raw_mask, s_remap);
+                    mine = top >= top_lo && top < top_hi;
+                }
+                if (mine) {
                     keep |= 1u << e;
-                    dig[e] = digit_of(tk.key[e], shift, raw_mask, s_remap);
+                    dig[e] = digit_of(key[e], shift, raw_mask, s_remap);
                     rank[e] = atomicAdd(&s_cnt[dig[e]], 1u);
                 }
             }
         }
         __syncthreads();
-        block_scan_bins(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 4);
-        const uint32_t total = s_misc[4];
+        block_scan_bins_t<NT>(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
+        const uint32_t total = s_misc[24];
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
+        for (int e = 0; e < E; e++) {
             if (keep & (1u << e)) {
                 uint32_t pos = s_cnt[dig[e]] + rank[e];
-                s_key[pos] = tk.key[e];
-                s_idx[pos] = (uint32_t)(tile0 + threadIdx.x * EPT + e);
+                s_key[pos] = key[e];
+                s_idx[pos] = (uint32_t)(tile0 + threadIdx.x * E + e);
             }
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < total; j += THREADS) {
+        for (uint32_t j = threadIdx.x; j < total; j += NT) {
             uint64_t k = s_key[j];
             uint32_t o = j + s_gdelta[digit_of(k, shift, raw_mask, s_remap)];
             out_key[o] = k;
@@ -507,8 +656,8 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool vali
 //                              + (#same digit in earlier waves of the tile)    [prefix over waves]
 // Records are staged in LDS in digit order and written out as contiguous runs per digit.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_SEG>
-__global__ void __launch_bounds__(THREADS)
+template <bool HAS_SEG, int NT, int E>
+__global__ void __launch_bounds__(NT)
 k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict__ in_idx,
                 const uint32_t* __restrict__ in_seg, uint32_t m, uint32_t nbins, int nbits,
                 uint32_t raw_bins, const uint16_t* __restrict__ gremap,
@@ -517,43 +666,48 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx,
                 uint32_t* __restrict__ out_seg)
 {
+    constexpr int TILEB = NT * E;
+    constexpr int NW = NT / WAVE;
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t NB = nbins;
     const uint32_t NBa = (NB + 3u) & ~3u;
-    constexpr int NW = THREADS / WAVE;
     uint32_t* s_gbase = reinterpret_cast<uint32_t*>(smem);  // NB
     uint32_t* s_gdelta = s_gbase + NBa;                     // NB
     uint32_t* s_tot = s_gdelta + NBa;                       // NB   tile count -> tile prefix
-    uint32_t* s_misc = s_tot + NBa;                         // 8
-    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 8);           // raw_bins (if remapped)
+    uint32_t* s_misc = s_tot + NBa;                         // 32
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 32);          // raw_bins (if remapped)
     uint8_t* s_union = reinterpret_cast<uint8_t*>(s_rm + (gremap ? ((raw_bins + 7u) & ~7u) : 0u));
     // union region: per-wave counters (NW*NB u16) during ranking, then the staging arrays
     uint16_t* s_wcnt = reinterpret_cast<uint16_t*>(s_union);
     uint64_t* s_key = reinterpret_cast<uint64_t*>(s_union);
-    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILE);
-    uint32_t* s_seg = s_idx + TILE;
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + TILEB);
+    uint32_t* s_seg = s_idx + TILEB;
 
     const uint32_t mask = raw_bins - 1;
     const uint32_t* row = table + (size_t)blockIdx.x * NB;
-    for (uint32_t i = threadIdx.x; i < NB; i += THREADS) s_gbase[i] = row[i] + binbase[i];
-    const uint16_t* s_remap = load_remap(gremap, s_rm, raw_bins);
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
+    const uint16_t* s_remap = nullptr;
+    if (gremap) {
+        for (uint32_t i = threadIdx.x; i < raw_bins; i += NT) s_rm[i] = gremap[i];
+        s_remap = s_rm;
+    }
     const uint32_t c0 = blockIdx.x * chunk;
     const uint32_t c1 = min(c0 + chunk, m);
     const int wv = threadIdx.x >> 6;
     const uint32_t ln = lane_id();
     const uint64_t lt_mask = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
 
-    for (uint32_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+    for (uint32_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
         __syncthreads();  // previous tile's copy-out done before the union region is reused
-        for (uint32_t i = threadIdx.x; i < (NW * NB + 1) / 2; i += THREADS)
+        for (uint32_t i = threadIdx.x; i < (NW * NB + 1) / 2; i += NT)
             reinterpret_cast<uint32_t*>(s_wcnt)[i] = 0;
         __syncthreads();
-        uint64_t key[EPT];
-        uint32_t idx[EPT], sg[EPT], dig[EPT], rank[EPT];
+        uint64_t key[E];
+        uint32_t idx[E], sg[E], dig[E], rank[E];
         uint32_t valid = 0;
-        const uint32_t strip0 = tile0 + wv * (EPT * WAVE);
+        const uint32_t strip0 = tile0 + wv * (E * WAVE);
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
+        for (int e = 0; e < E; e++) {
             uint32_t j = strip0 + e * WAVE + ln;
             if (j < c1) {
                 valid |= 1u << e;
@@ -566,7 +720,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
         }
         auto my = SUFR_LDS_VOLATILE(uint16_t, s_wcnt + (size_t)wv * NB);
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
+        for (int e = 0; e < E; e++) {
             bool v = valid & (1u << e);
             uint32_t d = digit_from_seg ? ((sg[e] >> shift) & mask) : digit_of(key[e], shift, mask, s_remap);
             dig[e] = d;
@@ -583,7 +737,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
         }
         __syncthreads();
         // per digit: exclusive prefix over waves (in place) and tile count
-        for (uint32_t d = threadIdx.x; d < NB; d += THREADS) {
+        for (uint32_t d = threadIdx.x; d < NB; d += NT) {
             uint32_t run = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) {
@@ -594,15 +748,15 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
             s_tot[d] = run;
         }
         __syncthreads();
-        block_scan_bins(s_tot, s_gbase, s_gdelta, NB, s_misc, s_misc + 4);
-        const uint32_t total = s_misc[4];
+        block_scan_bins_t<NT>(s_tot, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
+        const uint32_t total = s_misc[24];
         // final tile-local position of every record (registers), before the union region is reused
 #pragma unroll
-        for (int e = 0; e < EPT; e++)
+        for (int e = 0; e < E; e++)
             if (valid & (1u << e)) rank[e] += s_tot[dig[e]] + my[dig[e]];
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
+        for (int e = 0; e < E; e++) {
             if (valid & (1u << e)) {
                 s_key[rank[e]] = key[e];
                 s_idx[rank[e]] = idx[e];
@@ -610,7 +764,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
             }
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < total; j += THREADS) {
+        for (uint32_t j = threadIdx.x; j < total; j += NT) {
             uint64_t k = s_key[j];
             uint32_t sgv = HAS_SEG ? s_seg[j] : 0u;
             uint32_t d = digit_from_seg ? ((sgv >> shift) & mask) : digit_of(k, shift, mask, s_remap);
@@ -947,11 +1101,11 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
         // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
         if (act0) {
             dd0 += plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b);
-            k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u);
+            k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u, kp.packed);
         }
         if (act1) {
             dd1 += plain ? (uint32_t)kp.K : run_key_advance(k1, 64, kp.b);
-            k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u);
+            k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u, kp.packed);
         }
         plain = false;
     }
@@ -984,7 +1138,7 @@ k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __re
     __syncthreads();
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= m) return;
-    keys[e] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]]);
+    keys[e] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]], kp.packed);
 }
 
 // size of every large group (upper bound of (segment, sorted bits) in the sorted records) and the depth

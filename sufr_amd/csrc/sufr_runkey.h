@@ -22,11 +22,28 @@ SUFR_HD uint64_t load_u64_unaligned(const uint8_t* p)
     return v;
 }
 
+// x / bits for the handful of character widths that occur (bits is uniform across the wave, so this is a
+// scalar branch plus a multiply-shift instead of a software division)
+SUFR_HD uint32_t div_by_bits(uint32_t x, int bits)
+{
+    switch (bits) {
+        case 1: return x;
+        case 2: return x >> 1;
+        case 3: return x / 3u;
+        case 4: return x >> 2;
+        case 5: return x / 5u;
+        case 6: return x / 6u;
+        case 7: return x / 7u;
+        case 8: return x >> 3;
+        default: return x / 9u;
+    }
+}
+
 // common leading characters of two plain packed keys (K characters of `bits` bits from the top)
 SUFR_HD uint32_t plain_key_common(uint64_t a, uint64_t b, int bits, int K)
 {
     uint64_t x = a ^ b;
-    return x ? (uint32_t)(__builtin_clzll(x) / bits) : (uint32_t)K;
+    return x ? div_by_bits((uint32_t)__builtin_clzll(x), bits) : (uint32_t)K;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -65,7 +82,7 @@ SUFR_HD uint32_t run_key_common(uint64_t a, uint64_t b, int bits)
     RunTok ta = decode_run_token(a), tb = decode_run_token(b);
     if (ta.cls != tb.cls || ta.rem != tb.rem) return (ta.rem < tb.rem ? ta.rem : tb.rem);
     uint64_t x = (a ^ b) << ta.tokbits;
-    return ta.rem + (x ? (uint32_t)(__builtin_clzll(x) / bits) : (uint32_t)((64 - ta.tokbits) / bits));
+    return ta.rem + (x ? div_by_bits((uint32_t)__builtin_clzll(x), bits) : div_by_bits((uint32_t)(64 - ta.tokbits), bits));
 }
 
 // characters covered by the top `sorted_bits` of a run key (what a group defined on them shares)
@@ -73,7 +90,7 @@ SUFR_HD uint32_t run_key_advance(uint64_t key, int sorted_bits, int bits)
 {
     RunTok t = decode_run_token(key);
     int plain = sorted_bits - t.tokbits;
-    return t.rem + (plain > 0 ? (uint32_t)(plain / bits) : 0u);
+    return t.rem + (plain > 0 ? div_by_bits((uint32_t)plain, bits) : 0u);
 }
 
 // periodic extension length for period pi > 1: number of bytes from q on that equal the byte pi
@@ -101,7 +118,8 @@ SUFR_HD uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint
 // leaves the extension is smaller iff its byte is below the byte the extension predicts there.
 SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
                                                  const uint16_t* __restrict__ R, const uint16_t* s_lut,
-                                                 int bits, uint64_t q, uint32_t pi)
+                                                 int bits, uint64_t q, uint32_t pi,
+                                                 const uint8_t* __restrict__ packed = nullptr)
 {
     // q >= pi >= 1 and q <= n.  Loads are issued unconditionally (text and R are padded) so that the two
     // dependent rounds of memory traffic -- {c, text[q], R[q]} then {x, prediction, following words} --
@@ -117,8 +135,20 @@ SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
     const uint8_t* ta = text + after;
     const uint32_t x = ta[0];
     const uint32_t c = ta[-(int)pi];                   // what the periodic extension predicts at `after`
-    uint64_t w0 = load_u64_unaligned(ta), w1 = load_u64_unaligned(ta + 8);
-    uint64_t w2 = load_u64_unaligned(ta + 16), w3 = load_u64_unaligned(ta + 24);
+    // `packed` (optional): the whole text as a big-endian stream of `bits`-bit codes, zero past the end;
+    // the characters after the run are then one unaligned 9-byte read instead of a per-character loop
+    uint64_t pw = 0; uint32_t pw2 = 0; uint32_t ps = 0;
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (packed) {
+        const uint64_t o = after * (uint64_t)bits;
+        const uint8_t* pp = packed + (o >> 3);
+        ps = (uint32_t)(o & 7u);
+        pw = __builtin_bswap64(load_u64_unaligned(pp));
+        pw2 = pp[8];
+    } else {
+        w0 = load_u64_unaligned(ta); w1 = load_u64_unaligned(ta + 8);
+        w2 = load_u64_unaligned(ta + 16); w3 = load_u64_unaligned(ta + 24);
+    }
     const uint32_t cls = (after < n && x > c) ? 1u : 0u;
     const uint32_t v = rem + 1u;
     const int L = 31 - __builtin_clz(v);
@@ -128,7 +158,12 @@ SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
     const int tokbits = 1 + glen;
     uint64_t key = ((uint64_t)cls << 63) | (g << (63 - glen));
     int shift = 64 - tokbits;
-    const int nch = shift / bits;
+    const int nch = (int)div_by_bits((uint32_t)shift, bits);
+    if (packed) {
+        const uint64_t v = ps ? ((pw << ps) | ((uint64_t)pw2 >> (8 - ps))) : pw;   // codes from `after` on
+        const int spare = shift - nch * bits;                                        // unused low bits
+        return key | ((v >> tokbits) & (~0ull << spare));
+    }
     const uint64_t room = n - after;                   // characters that exist from `after` on
     const int live = room < (uint64_t)nch ? (int)room : nch;
     for (int j = 0; j < live; j++) {

@@ -18,9 +18,21 @@ void shim_run_lengths(const uint8_t* text, uint64_t n, uint16_t* R)
     }
 }
 uint64_t shim_make_run_key(const uint8_t* text, uint64_t n, const uint16_t* R, const uint16_t* lut, int bits,
-                           uint64_t q, uint32_t pi)
+                           uint64_t q, uint32_t pi, const uint8_t* packed)
 {
-    return sufr::make_run_key(text, n, R, lut, bits, q, pi);
+    return sufr::make_run_key(text, n, R, lut, bits, q, pi, packed);
+}
+// what k_pack_codes produces: big-endian stream of `bits`-bit codes, zero past the end
+void shim_pack_codes(const uint8_t* text, uint64_t n, const uint16_t* lut, int bits, uint8_t* packed, uint64_t cap)
+{
+    for (uint64_t i = 0; i < cap; i++) packed[i] = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        uint32_t c = lut[text[p]] & 0x7fu;
+        for (int k = 0; k < bits; k++) {
+            uint64_t bit = p * bits + k;                        // bit index from the MSB of byte 0
+            if ((c >> (bits - 1 - k)) & 1u) packed[bit >> 3] |= (uint8_t)(0x80u >> (bit & 7));
+        }
+    }
 }
 uint32_t shim_run_key_common(uint64_t a, uint64_t b, int bits) { return sufr::run_key_common(a, b, bits); }
 uint32_t shim_run_key_advance(uint64_t k, int sorted_bits, int bits) { return sufr::run_key_advance(k, sorted_bits, bits); }

@@ -23,7 +23,8 @@ def shim():
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(out), str(src)], check=True)
     L = C.CDLL(str(out))
     L.shim_run_lengths.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
-    L.shim_make_run_key.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32]
+    L.shim_make_run_key.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.shim_pack_codes.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.shim_make_run_key.restype = C.c_uint64
     L.shim_run_key_common.argtypes = [C.c_uint64, C.c_uint64, C.c_int]; L.shim_run_key_common.restype = C.c_uint32
     L.shim_run_key_advance.argtypes = [C.c_uint64, C.c_int, C.c_int]; L.shim_run_key_advance.restype = C.c_uint32
@@ -81,6 +82,8 @@ def test_run_keys_are_order_preserving_and_decode_exact_lcp(shim, ti, pi):
     R = np.zeros(n + PAD, dtype=np.uint16)
     shim.shim_run_lengths(buf.ctypes.data, n, R.ctypes.data)
     lut, bits = make_lut(t)
+    packed = np.zeros(n * bits // 8 + 128, dtype=np.uint8)
+    shim.shim_pack_codes(buf.ctypes.data, n, lut.ctypes.data, bits, packed.ctypes.data, packed.size)
     rng = np.random.default_rng(ti * 10 + pi)
     tb = t.tobytes()
     checked = 0
@@ -93,8 +96,13 @@ def test_run_keys_are_order_preserving_and_decode_exact_lcp(shim, ti, pi):
         if l < pi:
             continue
         d = int(rng.integers(pi, l + 1))          # any depth inside the common prefix (>= pi)
-        ka = shim.shim_make_run_key(buf.ctypes.data, n, R.ctypes.data, lut.ctypes.data, bits, a + d, pi)
-        kb = shim.shim_make_run_key(buf.ctypes.data, n, R.ctypes.data, lut.ctypes.data, bits, b + d, pi)
+        ka = shim.shim_make_run_key(buf.ctypes.data, n, R.ctypes.data, lut.ctypes.data, bits, a + d, pi, None)
+        kb = shim.shim_make_run_key(buf.ctypes.data, n, R.ctypes.data, lut.ctypes.data, bits, b + d, pi, None)
+        # the bit-packed fast path must produce the very same keys
+        assert ka == shim.shim_make_run_key(buf.ctypes.data, n, R.ctypes.data, lut.ctypes.data, bits, a + d, pi,
+                                            packed.ctypes.data)
+        assert kb == shim.shim_make_run_key(buf.ctypes.data, n, R.ctypes.data, lut.ctypes.data, bits, b + d, pi,
+                                            packed.ctypes.data)
         rest = l - d
         if ka == kb:
             adv = shim.shim_run_key_advance(ka, 64, bits)
