@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--bases", type=int, default=int(os.environ.get("SUFR_BENCH_BASES", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check SA/LCP properties on sampled ranks after timing")
+    ap.add_argument("--backend", default=os.environ.get("SUFR_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing N>1 on one GPU)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="smoke test: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,11 +105,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     gen, default_bases, flags, partitions, label = WORKLOADS[args.workload]
     bases = args.bases or default_bases
@@ -129,7 +138,7 @@ def main():
             # the only exchange of the path: {first, last, count} per rank, then the boundary-LCP stitch
             first = int(sa[0].item()) & 0xFFFFFFFF if s_local else 0
             last = int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0
-            bounds = shards.exchange_boundaries(first, last, s_local, dev, dist)
+            bounds = shards.exchange_boundaries(first, last, s_local, dev if args.backend == "nccl" else "cpu", dist)
             k = shards.stitched_first_lcp(
                 bounds, rank, lambda st, ln: sufr_amd.normalize(text[st:st + ln].cpu().numpy(), soft), n)
             if k is not None:
@@ -155,6 +164,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def allmax(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -162,10 +178,7 @@ def main():
         stats_acc.append(builder.stats.as_dict())
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = allmax(dt)
 
     s_total = totals["s_total"]
     if args.verify:

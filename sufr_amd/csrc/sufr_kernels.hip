@@ -966,15 +966,21 @@ __device__ __forceinline__ int mask_next_set(uint64_t M0, uint64_t M1, int slot,
     return m ? 64 + __builtin_ctzll(m) : none;
 }
 
-template <bool DEEP>
+// TIES_OUT (top level): records that still tie after the first ranking (equal whole key) are not iterated
+// on here -- almost every window has a few of them, and re-keying them in place would keep 128 lanes busy
+// for the sake of two or three.  Instead the window's tie runs are written back in sorted order and
+// described by four 64-bit lane masks (members / run heads); k_build_ties packs them into a dense level
+// whose finisher then works with all lanes active.
+template <bool DEEP, bool TIES_OUT>
 __global__ void __launch_bounds__(256)
-k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
+k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
          const uint32_t* __restrict__ segdepth, uint32_t m,
          const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ R,
          const uint16_t* __restrict__ glut, KeyParams kp, int sorted_bits,
          uint32_t* __restrict__ SA, uint32_t* __restrict__ LCP,
-         uint32_t* __restrict__ large_heads, uint32_t* __restrict__ large_count)
+         uint32_t* __restrict__ wl_flag, uint32_t* __restrict__ wl_head,
+         uint32_t* idx_writeback, unsigned long long* __restrict__ wmask, uint32_t* __restrict__ wcnt)
 {
     __shared__ uint64_t sh_key[4][128];
     __shared__ uint32_t sh_idx[4][128];
@@ -993,7 +999,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     auto si = SUFR_LDS_VOLATILE(uint32_t, sh_idx[wv]);
     auto sg = SUFR_LDS_VOLATILE(uint32_t, sh_gid[wv]);
     const int ln = (int)lane_id();
-    const int group_shift = 64 - sorted_bits;
+    const bool whole = sorted_bits == 0;            // groups are whole segments (no key bits sorted yet)
+    const int group_shift = whole ? 0 : 64 - sorted_bits;
     const uint32_t j0 = base + ln, j1 = base + 64 + ln;
     const bool in0 = j0 < m, in1 = j1 < m;
 
@@ -1017,11 +1024,12 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     uint64_t last0k = shfl64(k0, 63); uint32_t last0s = __shfl(sg0, 63, WAVE);
     if (ln == 0) { p0 = kprev; ps0 = sprev; p1 = last0k; ps1 = last0s; }
     const bool segdiff0 = DEEP && (ps0 != sg0), segdiff1 = DEEP && (ps1 != sg1);
-    const bool h0 = !in0 || (ln == 0 && !has_prev) || segdiff0 || ((p0 >> group_shift) != (k0 >> group_shift));
-    const bool h1 = !in1 || segdiff1 || ((p1 >> group_shift) != (k1 >> group_shift));
+    const bool h0 = !in0 || (ln == 0 && !has_prev) || segdiff0 ||
+                    (!whole && (p0 >> group_shift) != (k0 >> group_shift));
+    const bool h1 = !in1 || segdiff1 || (!whole && (p1 >> group_shift) != (k1 >> group_shift));
     uint64_t last1k = shfl64(k1, 63); uint32_t last1s = __shfl(sg1, 63, WAVE);
     const bool h128 = !has_next || (DEEP && snext != last1s) ||
-                      ((knext >> group_shift) != (last1k >> group_shift));
+                      (!whole && (knext >> group_shift) != (last1k >> group_shift));
     const uint64_t H0 = __ballot(h0), H1 = __ballot(h1);
 
     // first record of a segment (or of everything): its LCP belongs to the parent level / is 0
@@ -1038,16 +1046,22 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
     const int nx0 = mask_next_set(H0, H1, ln, none), nx1 = mask_next_set(H0, H1, 64 + ln, none);
     const bool own0 = in0 && g0 >= 0, own1 = in1 && g1 >= 0;       // group starts inside this window
     const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
-    if (own0 && h0 && !small0) {            // a large group is reported once, by its head slot
-        uint32_t at = atomicAdd(large_count, 1u);
-        large_heads[at] = j0;
+    // Only the window's last group can run past its end, so a window reports at most one large group:
+    // a flag and a head position per window, compacted afterwards by a scan (k_compact_large).  (Appending
+    // with one global atomic counter serialises: a quarter of all windows end in a crossing group.)
+    const bool lg0 = own0 && h0 && !small0, lg1 = own1 && h1 && !small1;
+    if (lg0) {
+        wl_head[wave] = j0;
         if (!first0) LCP[DEEP ? opos[j0] : j0] = lcp0;
         else if (!DEEP) LCP[j0] = 0;
     }
-    if (own1 && h1 && !small1) {
-        uint32_t at = atomicAdd(large_count, 1u);
-        large_heads[at] = j1;
+    if (lg1) {
+        wl_head[wave] = j1;
         if (!first1) LCP[DEEP ? opos[j1] : j1] = lcp1;
+    }
+    {
+        const uint64_t any_large = __ballot(lg0 || lg1);
+        if (ln == 0) wl_flag[wave] = any_large ? 1u : 0u;
     }
     bool act0 = small0 && !(h0 && nx0 == ln + 1);     // member of a small group with > 1 records
     bool act1 = small1 && !(h1 && nx1 == 64 + ln + 1);
@@ -1056,6 +1070,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
 
     bool plain = !DEEP;                       // format of the keys currently held
     const uint64_t max_round = n + 8;        // distinct suffixes separate within n characters
+    bool lt0 = false, lt1 = false;           // tie flags of the last ranking
     for (uint64_t round = 0; __ballot(act0 || act1) != 0ull && round < max_round; round++) {
         // ---- rank every active record inside its group (counting sort through LDS) ----------------
         sk[ln] = k0; sk[64 + ln] = k1; sg[ln] = gid0; sg[64 + ln] = gid1;
@@ -1098,6 +1113,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
         act1 = act1 && (tie1 || s1n);
         gid0 = act0 ? (uint32_t)ng0 : (0x10000u | (uint32_t)ln);
         gid1 = act1 ? (uint32_t)ng1 : (0x10000u | (uint32_t)(64 + ln));
+        lt0 = tie0; lt1 = tie1;
+        if (TIES_OUT) break;                  // tie runs go to the dense tie level (k_build_ties)
         // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
         if (act0) {
             dd0 += plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b);
@@ -1109,18 +1126,85 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idxs,
         }
         plain = false;
     }
+    if (TIES_OUT) {
+        // describe this window's tie runs: members (M) and run heads (H); write the members back in order
+        const uint64_t M0 = __ballot(act0), M1 = __ballot(act1);
+        const uint64_t Hd0 = __ballot(act0 && !lt0), Hd1 = __ballot(act1 && !lt1);
+        if (ln == 0) {
+            wmask[(size_t)wave * 4 + 0] = M0; wmask[(size_t)wave * 4 + 1] = M1;
+            wmask[(size_t)wave * 4 + 2] = Hd0; wmask[(size_t)wave * 4 + 3] = Hd1;
+            const uint32_t nwin = (m + 127u) / 128u;      // wcnt = [records per window | runs per window]
+            wcnt[wave] = (uint32_t)(__popcll(M0) + __popcll(M1));
+            wcnt[(size_t)nwin + wave] = (uint32_t)(__popcll(Hd0) + __popcll(Hd1));
+        }
+        if (act0) idx_writeback[j0] = i0;
+        if (act1) idx_writeback[j1] = i1;
+    }
     // ---- write the owned, completely ordered slots ------------------------------------------------
+    // (a tie-run member's SA entry, and its LCP unless it heads the run, come from the tie level)
     if (small0) {
+        const bool tied = TIES_OUT && act0;
         uint32_t o = DEEP ? opos[j0] : j0;
-        SA[o] = i0;
-        if (!first0) LCP[o] = lcp0;
-        else if (!DEEP) LCP[o] = 0;
+        if (!tied) SA[o] = i0;
+        if (!tied || !lt0) {
+            if (!first0) LCP[o] = lcp0;
+            else if (!DEEP) LCP[o] = 0;
+        }
     }
     if (small1) {
+        const bool tied = TIES_OUT && act1;
         uint32_t o = DEEP ? opos[j1] : j1;
-        SA[o] = i1;
-        if (!first1) LCP[o] = lcp1;
+        if (!tied) SA[o] = i1;
+        if ((!tied || !lt1) && !first1) LCP[o] = lcp1;
     }
+}
+
+// Dense level out of the tie runs that k_finish<false, true> described per window:
+// record t = rec_off[w] + (members below the slot) takes the written-back suffix of slot base + slot, its
+// segment is run_off[w] + (run heads at or below the slot) - 1, its output position is the slot itself;
+// every segment is re-keyed `depth0` characters in (the whole plain key matched).
+__global__ void __launch_bounds__(256)
+k_build_ties(const unsigned long long* __restrict__ wmask, const uint32_t* __restrict__ rec_off,
+             const uint32_t* __restrict__ run_off, const uint32_t* __restrict__ idxs, uint32_t m,
+             uint32_t depth0, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
+             uint32_t* __restrict__ opos_new, uint32_t* __restrict__ newdepth, uint8_t* __restrict__ newperiod)
+{
+    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint64_t base64 = (uint64_t)wave * 128;
+    if (base64 >= m) return;
+    const uint32_t base = (uint32_t)base64;
+    const int ln = (int)lane_id();
+    const uint64_t M0 = wmask[(size_t)wave * 4 + 0], M1 = wmask[(size_t)wave * 4 + 1];
+    const uint64_t H0 = wmask[(size_t)wave * 4 + 2], H1 = wmask[(size_t)wave * 4 + 3];
+    if ((M0 | M1) == 0ull) return;
+    const uint32_t ro = rec_off[wave], so = run_off[wave];
+    const uint64_t below = ln == 0 ? 0ull : (~0ull >> (64 - ln));
+    const uint64_t upto = below | (1ull << ln);
+    if ((M0 >> ln) & 1ull) {
+        uint32_t t = ro + (uint32_t)__popcll(M0 & below);
+        uint32_t sgm = so + (uint32_t)__popcll(H0 & upto) - 1u;
+        idx_new[t] = idxs[base + ln];
+        seg_new[t] = sgm;
+        opos_new[t] = base + ln;
+        if ((H0 >> ln) & 1ull) { newdepth[sgm] = depth0; newperiod[sgm] = 1; }
+    }
+    if ((M1 >> ln) & 1ull) {
+        uint32_t t = ro + (uint32_t)__popcll(M0) + (uint32_t)__popcll(M1 & below);
+        uint32_t sgm = so + (uint32_t)__popcll(H0) + (uint32_t)__popcll(H1 & upto) - 1u;
+        idx_new[t] = idxs[base + 64 + ln];
+        seg_new[t] = sgm;
+        opos_new[t] = base + 64 + ln;
+        if ((H1 >> ln) & 1ull) { newdepth[sgm] = depth0; newperiod[sgm] = 1; }
+    }
+}
+
+// heads[off[w]] = head position of window w's large group (off = exclusive scan of the window flags)
+__global__ void __launch_bounds__(256)
+k_compact_large(const uint32_t* __restrict__ wl_flag, const uint32_t* __restrict__ wl_off,
+                const uint32_t* __restrict__ wl_head, uint32_t nwin, uint32_t* __restrict__ heads)
+{
+    uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w < nwin && wl_flag[w]) heads[wl_off[w]] = wl_head[w];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1153,15 +1237,16 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= L) return;
-    const int group_shift = 64 - sorted_bits;
+    const bool whole = sorted_bits == 0;
+    const int group_shift = whole ? 0 : 64 - sorted_bits;
     uint32_t h = heads[k];
     uint64_t hk = keys[h];
-    uint64_t top = hk >> group_shift;
+    uint64_t top = whole ? 0ull : (hk >> group_shift);
     uint32_t sg = DEEP ? segs[h] : 0u;
     uint32_t lo = h + 1, hi = m;    // first position > h that is not in the group
     while (lo < hi) {
         uint32_t mid = lo + (hi - lo) / 2;
-        bool in_group = (!DEEP || segs[mid] == sg) && ((keys[mid] >> group_shift) == top);
+        bool in_group = (!DEEP || segs[mid] == sg) && (whole || (keys[mid] >> group_shift) == top);
         if (in_group) lo = mid + 1; else hi = mid;
     }
     uint32_t sz = lo - h;

@@ -90,6 +90,7 @@ SUFR_HD uint32_t run_key_advance(uint64_t key, int sorted_bits, int bits)
 {
     RunTok t = decode_run_token(key);
     int plain = sorted_bits - t.tokbits;
+    if (plain < 0) return 0u;          // the token itself is not fully shared: nothing is known to agree
     return t.rem + (plain > 0 ? div_by_bits((uint32_t)plain, bits) : 0u);
 }
 
