@@ -971,7 +971,11 @@ __device__ __forceinline__ int mask_next_set(uint64_t M0, uint64_t M1, int slot,
 // for the sake of two or three.  Instead the window's tie runs are written back in sorted order and
 // described by four 64-bit lane masks (members / run heads); k_build_ties packs them into a dense level
 // whose finisher then works with all lanes active.
-template <bool DEEP, bool TIES_OUT>
+// CROSS: second pass over the windows that flagged a group running past their end: the wave's window
+// now starts at that group's head, so any group of <= 128 records is finished here and only larger ones
+// stay flagged for the next level (without this pass a straddling small group would be deferred level
+// after level: one in five straddles again after repacking).
+template <bool DEEP, bool TIES_OUT, bool CROSS>
 __global__ void __launch_bounds__(256)
 k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
@@ -991,8 +995,9 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
 
     // one wave per window of 128 consecutive records; a group that crosses the window's end is "large"
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const uint64_t base64 = (uint64_t)wave * 128;
-    if (base64 >= m) return;
+    if ((uint64_t)wave * 128 >= m) return;
+    if (CROSS && !wl_flag[wave]) return;
+    const uint64_t base64 = CROSS ? (uint64_t)wl_head[wave] : (uint64_t)wave * 128;
     const uint32_t base = (uint32_t)base64;
     const int wv = threadIdx.x >> 6;
     auto sk = SUFR_LDS_VOLATILE(uint64_t, sh_key[wv]);
@@ -1044,12 +1049,16 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     const int g0 = mask_prev_set(H0, H1, ln), g1 = mask_prev_set(H0, H1, 64 + ln);
     const int none = h128 ? 128 : 1000;
     const int nx0 = mask_next_set(H0, H1, ln, none), nx1 = mask_next_set(H0, H1, 64 + ln, none);
-    const bool own0 = in0 && g0 >= 0, own1 = in1 && g1 >= 0;       // group starts inside this window
+    // group starts inside this window (CROSS: only the flagged group, whose head is slot 0)
+    const bool own0 = in0 && (CROSS ? g0 == 0 : g0 >= 0), own1 = in1 && (CROSS ? g1 == 0 : g1 >= 0);
     const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
     // Only the window's last group can run past its end, so a window reports at most one large group:
     // a flag and a head position per window, compacted afterwards by a scan (k_compact_large).  (Appending
     // with one global atomic counter serialises: a quarter of all windows end in a crossing group.)
     const bool lg0 = own0 && h0 && !small0, lg1 = own1 && h1 && !small1;
+    if (CROSS) {
+        if (__ballot(lg0) != 0ull) return;       // larger than a window: stays flagged for the next level
+    } else
     if (lg0) {
         wl_head[wave] = j0;
         if (!first0) LCP[DEEP ? opos[j0] : j0] = lcp0;
@@ -1059,7 +1068,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         wl_head[wave] = j1;
         if (!first1) LCP[DEEP ? opos[j1] : j1] = lcp1;
     }
-    {
+    if (!CROSS) {
         const uint64_t any_large = __ballot(lg0 || lg1);
         if (ln == 0) wl_flag[wave] = any_large ? 1u : 0u;
     }
@@ -1157,6 +1166,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         if (!tied) SA[o] = i1;
         if ((!tied || !lt1) && !first1) LCP[o] = lcp1;
     }
+    if (CROSS && ln == 0) wl_flag[wave] = 0u;       // finished here
 }
 
 // Dense level out of the tie runs that k_finish<false, true> described per window:
