@@ -51,6 +51,27 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic_bytes(workload: str):
+    """HBM bytes per launch of the radix-partition kernel from the committed rocprofv3 --pmc summary of
+    this same command (profiles/r*_pmc_<workload>.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for 16-B/lane streaming reads on gfx950, WRITE_SIZE as read).  None when no profile exists."""
+    import csv
+    import glob
+    files = sorted(glob.glob(str(ROOT / "profiles" / f"r*_pmc_{workload}.csv")))
+    if not files:
+        return None
+    fetch = write = None
+    for r in csv.DictReader(open(files[-1])):
+        if "k_scatter_text" in r["kernel"]:
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["largest_dispatch_value"])
+            if r["counter"] == "WRITE_SIZE":
+                write = float(r["largest_dispatch_value"])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: float = 15.0):
     """The oracle (C restatement of the reference algorithm, kind = "port") timed on this box's host
     cores on a bounded prefix of the same workload."""
@@ -214,7 +235,8 @@ def main():
                        "levels": st["num_levels"], "deep_records": st["deep_records"]},
             "roofline": {"kernel": "k_scatter_text (radix partition, first pass)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(args.workload) if world == 1 and not args.bases else None,
                          "algorithmic_bytes": alg_bytes, "ms": avg["ms_partition"]},
             "device_ms": avg,
         }

@@ -128,7 +128,7 @@ struct TileKeys {
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, uint32_t raw_mask, const uint16_t* s_remap)
 {
     uint32_t r = (uint32_t)(key >> shift) & raw_mask;
-    return s_remap ? (uint32_t)s_remap[r] : r;
+    return s_remap ? (uint32_t)s_remap[r] : r;     // s_remap: LDS copy, or the global table (L1-resident)
 }
 
 __device__ __forceinline__ void load_lut(const uint16_t* __restrict__ glut, uint16_t* s_lut)
@@ -334,7 +334,7 @@ template <int B>
 __global__ void __launch_bounds__(THREADS)
 k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
             const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
-            uint32_t top_lo, uint32_t top_hi, uint32_t* __restrict__ table)
+            uint32_t top_lo, uint32_t top_hi, uint32_t tile_stride, uint32_t* __restrict__ table)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                  // nbins
@@ -349,10 +349,11 @@ k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __rest
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
     uint4 nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
-    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += (uint64_t)TILE * tile_stride) {
         __syncthreads();
         const uint4 mine = nxt;
-        if (tile0 + TILE < c1) nxt = reinterpret_cast<const uint4*>(text + tile0 + TILE)[threadIdx.x];
+        if (tile0 + (uint64_t)TILE * tile_stride < c1)
+            nxt = reinterpret_cast<const uint4*>(text + tile0 + (uint64_t)TILE * tile_stride)[threadIdx.x];
         TileKeys tk;
         tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);
 #pragma unroll
@@ -541,6 +542,8 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
     const uint32_t* row = table + (size_t)blockIdx.x * NB;
     for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
     for (int i = threadIdx.x; i < 256; i += NT) s_lut[i] = glut[i];
+    // (tables stay in LDS: reading them through L1 instead measured slower, and a pointer that may be
+    //  either LDS or global turns every lookup into a FLAT access)
     const uint16_t* s_remap = nullptr;
     if (gremap) {
         for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += NT) s_rm[i] = gremap[i];
@@ -562,9 +565,18 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
         }
         __syncthreads();
         uint64_t key[E];
-        uint32_t elig;
-        if constexpr (B > 0) build_keys_t<B, E>(s_tile, key, elig);
-        else build_keys_generic_t<E>(s_tile, s_lut, tile0, n, kp.b, kp.K, key, elig);
+        uint32_t elig = 0;
+        if constexpr (B > 0) {
+            // whole threads (and often whole waves) sit inside runs of ineligible bytes ('N' runs are half
+            // of a soft-masked genome): peek at the eligibility bits before building any key
+            const uint2* own = reinterpret_cast<const uint2*>(s_tile + threadIdx.x * E);
+            uint32_t any = 0;
+#pragma unroll
+            for (int v = 0; v < E / 8; v++) { uint2 q = own[v]; any |= (q.x | q.y) & 0x80808080u; }
+            if (any || !kp.skip_inelig) build_keys_t<B, E>(s_tile, key, elig);
+        } else {
+            build_keys_generic_t<E>(s_tile, s_lut, tile0, n, kp.b, kp.K, key, elig);
+        }
         uint32_t rank[E], dig[E];
         uint32_t keep = 0;
 #pragma unroll

@@ -269,4 +269,18 @@ def test_elegans_config_c3_properties(oracle):
     check_sa_lcp_properties(norm, sa.cpu().numpy().view(np.uint32), lcp.cpu().numpy().view(np.uint32),
                             is_dna=True, allow_ambiguity=False, sample=200_000, seed=1)
     assert st["num_suffixes"] == 100_286_402 - 6      # 6 delimiter positions are not suffix starts
+    # the same text in 3 prefix-bucket shards (splitters from the sampled k-mer histogram): concatenation
+    # must equal the unsharded arrays except for the first LCP entry of shards 1.., which is the stitch
+    full_sa, full_lcp = sa.clone(), lcp.clone()
+    off = 0
+    for r in range(3):
+        psa, plcp = db.sort(x, is_dna=True, raw_text=True, shard_index=r, num_shards=3)
+        k = psa.numel()
+        assert k > 0 and torch.equal(psa, full_sa[off:off + k])
+        assert torch.equal(plcp[1:], full_lcp[off + 1:off + k])
+        if r > 0:
+            a, b = int(full_sa[off - 1]) & 0xFFFFFFFF, int(psa[0]) & 0xFFFFFFFF
+            assert sufr_amd.lcp_pair(norm, a, b) == int(full_lcp[off])
+        off += k
+    assert off == full_sa.numel()
     db.close()

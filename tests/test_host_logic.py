@@ -161,3 +161,17 @@ def test_cli_usage_and_errors(tmp_path):
         r = subprocess.run([exe, "create", "--dna", "-o", str(tmp_path / "o.sufr"), str(GOLDEN / "inputs" / "1.fa")],
                            capture_output=True, text=True)
         assert r.returncode == 1 and r.stderr.startswith("Error: ")
+
+
+def test_no_flat_instructions_in_the_kernels():
+    """Wave-private exchanges through LDS rely on ds_* ordering; a pointer that loses the LDS address space
+    makes hipcc emit FLAT accesses, which are unordered.  The device ISA of every
+    sufr kernel must be free of them."""
+    csrc = sufr_amd.LIB_PATH.parents[1]
+    r = subprocess.run(["make", "-C", str(csrc), "asm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = (csrc / "_build" / "sufr_kernels.s").read_text()
+    bad = [ln for ln in asm.splitlines() if re.search(r"\bflat_(load|store|atomic)", ln)]
+    assert not bad, bad[:5]
+    # and no kernel spills to scratch
+    assert all(int(v) == 0 for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", asm))
