@@ -577,6 +577,13 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
         } else {
             build_keys_generic_t<E>(s_tile, s_lut, tile0, n, kp.b, kp.K, key, elig);
         }
+        if (kp.ablate & 4) {       // timing experiment: stop after the key build
+            uint64_t acc = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) if (elig & (1u << e)) acc ^= key[e];
+            if (acc == 0x123456789ull) out_key[0] = acc;
+            continue;
+        }
         uint32_t rank[E], dig[E];
         uint32_t keep = 0;
 #pragma unroll
@@ -595,6 +602,15 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
                 }
             }
         }
+        // keys go to LDS linearly (own slots: conflict-free 16-byte stores); the suffix index is implicit
+        // in the slot, so only a 4-byte (slot, digit) entry is scattered to the record's ranked position
+        if (keep) {
+            uint4* kd = reinterpret_cast<uint4*>(s_key + threadIdx.x * E);
+#pragma unroll
+            for (int v = 0; v < E / 2; v++)
+                kd[v] = make_uint4((uint32_t)key[2 * v], (uint32_t)(key[2 * v] >> 32), (uint32_t)key[2 * v + 1],
+                                   (uint32_t)(key[2 * v + 1] >> 32));
+        }
         __syncthreads();
         block_scan_bins_t<NT>(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
         const uint32_t total = s_misc[24];
@@ -602,16 +618,21 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
         for (int e = 0; e < E; e++) {
             if (keep & (1u << e)) {
                 uint32_t pos = s_cnt[dig[e]] + rank[e];
-                s_key[pos] = key[e];
-                s_idx[pos] = (uint32_t)(tile0 + threadIdx.x * E + e);
+                s_idx[pos] = ((uint32_t)(threadIdx.x * E + e) << 12) | dig[e];     // s_idx doubles as the permutation
             }
         }
         __syncthreads();
+        if (kp.ablate & 2) continue;      // timing experiment: no copy-out at all
         for (uint32_t j = threadIdx.x; j < total; j += NT) {
-            uint64_t k = s_key[j];
-            uint32_t o = j + s_gdelta[digit_of(k, shift, raw_mask, s_remap)];
-            out_key[o] = k;
-            out_idx[o] = s_idx[j];
+            const uint32_t pe = s_idx[j];
+            const uint32_t slot = pe >> 12, d = pe & 0xfffu;
+            const uint32_t o = j + s_gdelta[d];
+            if (kp.ablate & 1) {          // timing experiment: LDS side of the copy-out, no global stores
+                if (s_key[slot] == 0x123456789ull && o == 77) out_idx[0] = 1;
+                continue;
+            }
+            out_key[o] = s_key[slot];
+            out_idx[o] = (uint32_t)(tile0 + slot);
         }
     }
 }
