@@ -63,45 +63,74 @@ __device__ __forceinline__ uint64_t shfl64_up1(uint64_t v)
 // 256-bin byte histogram of the NORMALISED text.  The histogram drives the alphabet -> dense code
 // table, the eligible-suffix count and the pass-count heuristic.
 // LDS histogram is replicated 32x (bin-major) so that lanes l and l+32 share a copy and every
-// lane of a half-wave hits its own bank.
+// lane of a half-wave hits its own bank.  The same pass records, per 4096-byte tile, the first position
+// where a run of equal bytes ends (first_end[], the look-ahead table of k_run_fill).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n,
-                     int normalize, int ignore_softmask, unsigned long long* __restrict__ ghist)
+                     int normalize, int ignore_softmask, unsigned long long* __restrict__ ghist,
+                     uint32_t* __restrict__ first_end)
 {
     __shared__ uint32_t h[256 * 32];
+    __shared__ uint8_t s_first[256 + 4];
+    __shared__ uint32_t s_min;
     for (int i = threadIdx.x; i < 256 * 32; i += 256) h[i] = 0;
     __syncthreads();
     const uint32_t copy = threadIdx.x & 31u;
-    const uint64_t nvec = n / 16;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
-        uint4 w = reinterpret_cast<const uint4*>(in)[v];
-        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    auto norm = [&](uint32_t b) -> uint32_t {
+        if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
+        return b;
+    };
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * TILE + (uint64_t)threadIdx.x * 16;
+        uint32_t by[17];
+        if (threadIdx.x == 0) s_min = 0xffffffffu;
+        if (p0 + 16 <= n) {
+            uint4 w = *reinterpret_cast<const uint4*>(in + p0);
+            uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t x = ws[k], y = 0;
+            for (int k = 0; k < 4; k++) {
+                uint32_t y = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t b = (x >> (8 * j)) & 0xffu;
-                if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
-                y |= b << (8 * j);
-                atomicAdd(&h[b * 32 + copy], 1u);
+                for (int j = 0; j < 4; j++) {
+                    uint32_t b = norm((ws[k] >> (8 * j)) & 0xffu);
+                    by[4 * k + j] = b;
+                    y |= b << (8 * j);
+                    atomicAdd(&h[b * 32 + copy], 1u);
+                }
+                ws[k] = y;
             }
-            ws[k] = y;
+            *reinterpret_cast<uint4*>(out + p0) = make_uint4(ws[0], ws[1], ws[2], ws[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                by[e] = 0;
+                if (p0 + e < n) {
+                    uint32_t b = norm(in[p0 + e]);
+                    by[e] = b;
+                    out[p0 + e] = (uint8_t)b;
+                    atomicAdd(&h[b * 32 + copy], 1u);
+                }
+            }
         }
-        reinterpret_cast<uint4*>(out)[v] = make_uint4(ws[0], ws[1], ws[2], ws[3]);
-    }
-    // tail bytes
-    if (blockIdx.x == 0) {
-        for (uint64_t i = nvec * 16 + threadIdx.x; i < n; i += 256) {
-            uint32_t b = in[i];
-            if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
-            out[i] = (uint8_t)b;
-            atomicAdd(&h[b * 32 + copy], 1u);
+        s_first[threadIdx.x] = (uint8_t)by[0];
+        __syncthreads();
+        // byte after this thread's 16: the next thread's first byte, or the next tile's first byte
+        if (threadIdx.x < 255) by[16] = s_first[threadIdx.x + 1];
+        else by[16] = (p0 + 16 < n) ? norm(in[p0 + 16]) : 0u;
+        // first position of the tile where a run of equal bytes ends (k_run_fill's look-ahead table)
+        uint32_t best = 0xffffffffu;
+#pragma unroll
+        for (int e = 15; e >= 0; e--) {
+            uint64_t p = p0 + e;
+            if (p < n && (p == n - 1 || by[e] != by[e + 1])) best = (uint32_t)p;
         }
+        if (best != 0xffffffffu) atomicMin(&s_min, best);
+        __syncthreads();
+        if (threadIdx.x == 0) first_end[tile] = s_min;
+        __syncthreads();
     }
-    __syncthreads();
     {
         uint32_t sum = 0;
         for (int c = 0; c < 32; c++) sum += h[threadIdx.x * 32 + ((c + threadIdx.x) & 31)];
@@ -298,7 +327,7 @@ k_pack_codes(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __res
 template <int B>
 __global__ void __launch_bounds__(THREADS)
 k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
-                 KeyParams kp, uint64_t chunk, uint32_t* __restrict__ flags)
+                 KeyParams kp, uint64_t chunk, uint32_t* __restrict__ flags, uint8_t* __restrict__ packed)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* s_flag = smem;                                              // raw_bins
@@ -318,6 +347,27 @@ k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (tile0 + threadIdx.x * EPT + e < n) s_flag[(uint32_t)(tk.key[e] >> kp.top_shift)] = 1;
+        if constexpr (B > 0 && B <= 4) {
+            // the same code bytes, bit-packed big-endian (what k_pack_codes would produce)
+            if (packed) {
+                uint4 q = reinterpret_cast<const uint4*>(s_tile)[threadIdx.x];
+                uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+                uint64_t V = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) V = (V << B) | (uint64_t)((ws[j >> 2] >> (8 * (j & 3))) & 0x7fu);
+                __syncthreads();                        // everyone has read its codes: reuse the tile buffer
+                uint16_t* s_pack = reinterpret_cast<uint16_t*>(s_tile);
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    uint32_t hh = (uint32_t)(V >> (16 * (B - 1 - k))) & 0xffffu;
+                    s_pack[threadIdx.x * B + k] = (uint16_t)((hh >> 8) | (hh << 8));
+                }
+                __syncthreads();
+                uint4* dst = reinterpret_cast<uint4*>(packed + (tile0 / TILE) * (uint64_t)(TILE * B / 8));
+                const uint4* src = reinterpret_cast<const uint4*>(s_pack);
+                for (int v = threadIdx.x; v < TILE * B / 8 / 16; v += THREADS) dst[v] = src[v];
+            }
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS)
@@ -876,34 +926,9 @@ k_scan_bins(const uint32_t* __restrict__ bintot, uint32_t nbins, uint32_t* __res
 // the end of the text.  Genomes built with --ignore-softmask are ~50 % 'N' in runs of hundreds to
 // millions of bytes; the reference walks through them byte by byte inside find_lcp
 // (sufr_builder.rs:301-331).  With R a whole run is compared in O(1) (see make_run_key).
-//   k_run_first: per 4096-byte tile, position of the first run end (0xffffffff if the tile has none)
+//   (per 4096-byte tile, the position of its first run end comes from k_normalize_bytehist)
 //   k_run_fill:  R for every position, looking at most 16 tiles ahead (the saturation horizon)
 // ---------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256)
-k_run_first(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ first_end)
-{
-    __shared__ uint32_t s_min;
-    if (threadIdx.x == 0) s_min = 0xffffffffu;
-    __syncthreads();
-    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * EPT;
-    uint32_t best = 0xffffffffu;
-    if (p0 < n) {
-        // bytes p0 .. p0+16 (the text is padded, reading past n is safe)
-        uint4 w = *reinterpret_cast<const uint4*>(text + p0);
-        uint32_t ws[5] = {w.x, w.y, w.z, w.w, (uint32_t)text[p0 + EPT]};
-#pragma unroll
-        for (int e = EPT - 1; e >= 0; e--) {
-            uint64_t p = p0 + e;
-            uint32_t a = (ws[e >> 2] >> (8 * (e & 3))) & 0xffu;
-            uint32_t b = (ws[(e + 1) >> 2] >> (8 * ((e + 1) & 3))) & 0xffu;
-            if (p < n && (p == n - 1 || a != b)) best = (uint32_t)p;
-        }
-    }
-    if (best != 0xffffffffu) atomicMin(&s_min, best);
-    __syncthreads();
-    if (threadIdx.x == 0) first_end[blockIdx.x] = s_min;
-}
 
 __global__ void __launch_bounds__(256)
 k_run_fill(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ first_end,
@@ -937,10 +962,27 @@ k_run_fill(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
         s_next = nx;
     }
     __syncthreads();
-    // nearest run end after this thread's span: suffix-min over the later threads, then later tiles
-    uint32_t after = 0xffffffffu;
-    for (int t = threadIdx.x + 1; t < 256 && after == 0xffffffffu; t++) after = s_thr[t];
-    if (after == 0xffffffffu) after = s_next;
+    // nearest run end after this thread's span: exclusive suffix-min over the later threads (positions
+    // grow with the thread index, so the minimum is the nearest), then the later tiles
+    uint32_t after;
+    {
+        const int ln = (int)lane_id();
+        uint32_t v = best;                                   // inclusive suffix-min inside the wave
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            uint32_t t = __shfl_down(v, o, WAVE);
+            if (ln + o < WAVE) v = min(v, t);
+        }
+        uint32_t ex = __shfl_down(v, 1, WAVE);
+        if (ln == 63) ex = 0xffffffffu;
+        // later waves: their first-lane inclusive value is the wave minimum; s_thr was written above
+        for (int w = (threadIdx.x >> 6) + 1; w < 4 && ex == 0xffffffffu; w++) {
+            uint32_t m2 = 0xffffffffu;
+            for (int t = w * 64; t < w * 64 + 64 && m2 == 0xffffffffu; t += 1) m2 = s_thr[t];
+            ex = m2;
+        }
+        after = ex != 0xffffffffu ? ex : s_next;
+    }
     if (p0 < n) {
         uint16_t out[EPT];
 #pragma unroll
