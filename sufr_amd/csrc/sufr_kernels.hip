@@ -1059,7 +1059,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          const uint16_t* __restrict__ glut, KeyParams kp, int sorted_bits,
          uint32_t* __restrict__ SA, uint32_t* __restrict__ LCP,
          uint32_t* __restrict__ wl_flag, uint32_t* __restrict__ wl_head,
-         uint32_t* idx_writeback, unsigned long long* __restrict__ wmask, uint32_t* __restrict__ wcnt)
+         uint32_t* idx_writeback, unsigned long long* __restrict__ wmask, uint32_t* __restrict__ wcnt,
+         uint32_t ncross)
 {
     __shared__ uint64_t sh_key[4][128];
     __shared__ uint32_t sh_idx[4][128];
@@ -1069,11 +1070,13 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     __syncthreads();
 
     // one wave per window of 128 consecutive records; a group that crosses the window's end is "large"
+    // CROSS: wave i works on the i-th flagged group (wl_head = compact list of their heads, wl_flag[i] is
+    // set to 1 while the group stays large and to 0 once it has been finished here)
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if ((uint64_t)wave * 128 >= m) return;
-    if (CROSS && !wl_flag[wave]) return;
+    if (CROSS ? (wave >= ncross) : ((uint64_t)wave * 128 >= m)) return;
     const uint64_t base64 = CROSS ? (uint64_t)wl_head[wave] : (uint64_t)wave * 128;
     const uint32_t base = (uint32_t)base64;
+    if (CROSS && (threadIdx.x & 63u) == 0) wl_flag[wave] = 1u;
     const int wv = threadIdx.x >> 6;
     auto sk = SUFR_LDS_VOLATILE(uint64_t, sh_key[wv]);
     auto si = SUFR_LDS_VOLATILE(uint32_t, sh_idx[wv]);
@@ -1254,32 +1257,32 @@ k_build_ties(const unsigned long long* __restrict__ wmask, const uint32_t* __res
              uint32_t depth0, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
              uint32_t* __restrict__ opos_new, uint32_t* __restrict__ newdepth, uint8_t* __restrict__ newperiod)
 {
-    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const uint64_t base64 = (uint64_t)wave * 128;
+    // one thread per window: a window holds only a couple of tied records on average
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t base64 = (uint64_t)w * 128;
     if (base64 >= m) return;
     const uint32_t base = (uint32_t)base64;
-    const int ln = (int)lane_id();
-    const uint64_t M0 = wmask[(size_t)wave * 4 + 0], M1 = wmask[(size_t)wave * 4 + 1];
-    const uint64_t H0 = wmask[(size_t)wave * 4 + 2], H1 = wmask[(size_t)wave * 4 + 3];
-    if ((M0 | M1) == 0ull) return;
-    const uint32_t ro = rec_off[wave], so = run_off[wave];
-    const uint64_t below = ln == 0 ? 0ull : (~0ull >> (64 - ln));
-    const uint64_t upto = below | (1ull << ln);
-    if ((M0 >> ln) & 1ull) {
-        uint32_t t = ro + (uint32_t)__popcll(M0 & below);
-        uint32_t sgm = so + (uint32_t)__popcll(H0 & upto) - 1u;
-        idx_new[t] = idxs[base + ln];
-        seg_new[t] = sgm;
-        opos_new[t] = base + ln;
-        if ((H0 >> ln) & 1ull) { newdepth[sgm] = depth0; newperiod[sgm] = 1; }
-    }
-    if ((M1 >> ln) & 1ull) {
-        uint32_t t = ro + (uint32_t)__popcll(M0) + (uint32_t)__popcll(M1 & below);
-        uint32_t sgm = so + (uint32_t)__popcll(H0) + (uint32_t)__popcll(H1 & upto) - 1u;
-        idx_new[t] = idxs[base + 64 + ln];
-        seg_new[t] = sgm;
-        opos_new[t] = base + 64 + ln;
-        if ((H1 >> ln) & 1ull) { newdepth[sgm] = depth0; newperiod[sgm] = 1; }
+    uint64_t M[2] = {wmask[(size_t)w * 4 + 0], wmask[(size_t)w * 4 + 1]};
+    uint64_t H[2] = {wmask[(size_t)w * 4 + 2], wmask[(size_t)w * 4 + 3]};
+    if ((M[0] | M[1]) == 0ull) return;
+    uint32_t t = rec_off[w];
+    uint32_t sgm = run_off[w] - 1u;          // incremented at every run head
+    for (int half = 0; half < 2; half++) {
+        uint64_t mm = M[half];
+        while (mm) {
+            const int bit = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t slot = (uint32_t)(half * 64 + bit);
+            if ((H[half] >> bit) & 1ull) {
+                sgm++;
+                newdepth[sgm] = depth0;
+                newperiod[sgm] = 1;
+            }
+            idx_new[t] = idxs[base + slot];
+            seg_new[t] = sgm;
+            opos_new[t] = base + slot;
+            t++;
+        }
     }
 }
 
