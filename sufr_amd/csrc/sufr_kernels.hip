@@ -739,7 +739,28 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool vali
 //                              + (#same digit in earlier waves of the tile)    [prefix over waves]
 // Records are staged in LDS in digit order and written out as contiguous runs per digit.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_SEG, int NT, int E>
+// Lanes holding the same digit as this lane, as two 32-bit half masks.  Per bit: t = -bit (one v_bfe_i32),
+// one ballot, and per half an xnor + and:  same_k = ~(ballot_k ^ t).
+template <int NBITS>
+__device__ __forceinline__ void match_digit_t(uint32_t d, int nbits, bool valid, uint32_t& mlo, uint32_t& mhi)
+{
+    const uint64_t vm = __ballot(valid);
+    mlo = (uint32_t)vm; mhi = (uint32_t)(vm >> 32);
+    auto step = [&](int k) {
+        const int32_t t = ((int32_t)(d << (31 - k))) >> 31;      // 0 or -1
+        const uint64_t bk = __ballot(t != 0);
+        mlo &= ~((uint32_t)bk ^ (uint32_t)t);
+        mhi &= ~((uint32_t)(bk >> 32) ^ (uint32_t)t);
+    };
+    if constexpr (NBITS > 0) {
+#pragma unroll
+        for (int k = 0; k < NBITS; k++) step(k);
+    } else {
+        for (int k = 0; k < nbits; k++) step(k);
+    }
+}
+
+template <bool HAS_SEG, int NT, int E, int NBITS>
 __global__ void __launch_bounds__(NT)
 k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict__ in_idx,
                 const uint32_t* __restrict__ in_seg, uint32_t m, uint32_t nbins, int nbits,
@@ -747,8 +768,17 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 int shift, int digit_from_seg, uint32_t chunk,
                 const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
                 uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx,
-                uint32_t* __restrict__ out_seg)
+                uint32_t* __restrict__ out_seg, int ablate, unsigned long long* __restrict__ stamps)
 {
+    // diagnostic build path (ablate & 16): thread 0 accumulates s_memtime deltas per phase into stamps[]
+    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamping = (ablate & 16) && threadIdx.x == 0;
+#define SUFR_STAMP(i)                                                        \
+    if (stamping) {                                                          \
+        unsigned long long t_now = __builtin_amdgcn_s_memtime();             \
+        t_acc[i] += t_now - t_prev;                                          \
+        t_prev = t_now;                                                      \
+    }
     constexpr int TILEB = NT * E;
     constexpr int NW = NT / WAVE;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -778,8 +808,8 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
     const uint32_t c1 = min(c0 + chunk, m);
     const int wv = threadIdx.x >> 6;
     const uint32_t ln = lane_id();
-    const uint64_t lt_mask = (ln == 0) ? 0ull : (~0ull >> (64 - ln));
 
+    if (stamping) t_prev = __builtin_amdgcn_s_memtime();
     for (uint32_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
         __syncthreads();  // previous tile's copy-out done before the union region is reused
         for (uint32_t i = threadIdx.x; i < (NW * NB + 1) / 2; i += NT)
@@ -801,24 +831,37 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 key[e] = 0; idx[e] = 0; sg[e] = 0;
             }
         }
+        if (ablate & 4) {          // timing experiment: loads only
+            uint64_t acc = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) acc ^= key[e] + idx[e];
+            if (acc == 0x123456789ull) out_key[0] = acc;
+            continue;
+        }
+        SUFR_STAMP(0)        // zero counters + issue loads
+        if (ablate & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        SUFR_STAMP(6)        // (diagnostic) wait for the tile's loads
         auto my = SUFR_LDS_VOLATILE(uint16_t, s_wcnt + (size_t)wv * NB);
+        // digits of all E records first (independent LDS look-ups in flight together) ...
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            dig[e] = digit_from_seg ? ((sg[e] >> shift) & mask) : digit_of(key[e], shift, mask, s_remap);
+        // ... then E straight-line ranking rounds (records strip0 + e*64 + lane)
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            bool v = valid & (1u << e);
-            uint32_t d = digit_from_seg ? ((sg[e] >> shift) & mask) : digit_of(key[e], shift, mask, s_remap);
-            dig[e] = d;
-            uint64_t mm = match_digit(d, nbits, v);
-            uint32_t before = 0;
-            if (v) {
-                before = my[d];
-                uint32_t lower = __popcll(mm & lt_mask);
-                rank[e] = before + lower;
-                if (lower == 0) my[d] = (uint16_t)(before + __popcll(mm));
-            } else {
-                rank[e] = 0;
-            }
+            const bool v = valid & (1u << e);
+            const uint32_t d = dig[e];
+            uint32_t mlo, mhi;
+            match_digit_t<NBITS>(d, nbits, v, mlo, mhi);
+            const uint32_t before = my[d];                 // lanes without a record read a harmless slot
+            // peers in lower lanes: v_mbcnt counts the mask bits below this lane directly
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            rank[e] = before + lower;
+            if (v && lower == 0) my[d] = (uint16_t)(before + __popc(mlo) + __popc(mhi));
         }
+        SUFR_STAMP(1)        // load wait + digits + ranking rounds
         __syncthreads();
+        SUFR_STAMP(2)        // barrier wait
         // per digit: exclusive prefix over waves (in place) and tile count
         for (uint32_t d = threadIdx.x; d < NB; d += NT) {
             uint32_t run = 0;
@@ -833,6 +876,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
         __syncthreads();
         block_scan_bins_t<NT>(s_tot, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
         const uint32_t total = s_misc[24];
+        SUFR_STAMP(3)        // wave prefix + bin scan
         // final tile-local position of every record (registers), before the union region is reused
 #pragma unroll
         for (int e = 0; e < E; e++)
@@ -847,16 +891,23 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
             }
         }
         __syncthreads();
+        SUFR_STAMP(4)        // final positions + LDS staging
+        if (ablate & 2) continue;      // timing experiment: no copy-out
         for (uint32_t j = threadIdx.x; j < total; j += NT) {
             uint64_t k = s_key[j];
             uint32_t sgv = HAS_SEG ? s_seg[j] : 0u;
             uint32_t d = digit_from_seg ? ((sgv >> shift) & mask) : digit_of(k, shift, mask, s_remap);
             uint32_t o = j + s_gdelta[d];
+            if (ablate & 1) { if (k == 0x123456789ull && o == 77) out_idx[0] = 1; continue; }   // no global stores
             out_key[o] = k;
             out_idx[o] = s_idx[j];
             if (HAS_SEG) out_seg[o] = sgv;
         }
+        SUFR_STAMP(5)        // copy-out
     }
+    if (stamping)
+        for (int i = 0; i < 7; i++) atomicAdd(&stamps[i], t_acc[i]);
+#undef SUFR_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
