@@ -102,7 +102,12 @@ int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_s
  * only the shard_index-th prefix-bucket range (shards are balanced on the device from the k-mer
  * histogram; concatenating shards 0..num_shards-1 gives the full arrays, and the first LCP entry of
  * every shard but the first must be stitched with sufr_hip_lcp_pair).
- * max_query_len / seed_mask: pass 0 / NULL; non-default values return SUFR_HIP_E_UNSUPPORTED.
+ * max_query_len (0 = none) and seed_mask (NULL = none) are the reference's -m / -s builds
+ * (sufr_builder.rs:272-300, 310-314, 350-359, 668-683): the seed-mask order (care characters, ties in
+ * descending position, LCP in care characters) is reproduced exactly; for max_query_len, where the
+ * reference's arrays depend on pivots and merge order, the canonical form is returned (order of the first
+ * L characters, ties in descending position, LCP = min(exact, L)).  Both are
+ * single-shard builds: with num_shards > 1 they return SUFR_HIP_E_UNSUPPORTED.
  * num_partitions and random_seed are accepted for signature parity: the result does not depend on
  * them (pivots are replaced by on-device histogram splitters). */
 int sufr_hip_sort_device_u32(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,

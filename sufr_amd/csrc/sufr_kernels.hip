@@ -1528,6 +1528,148 @@ k_check_sorted(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
     if (bad) atomicMin(first_bad, j);
 }
 
+// ---------------------------------------------------------------------------------------------
+// --max-query-len builds (sufr_builder.rs:310-314, 350-359, 668-683).  Suffixes that agree on their
+// first L characters are equal for the reference's comparator; its merge then emits the larger position
+// first (701-712).  The exact arrays are built first; these kernels cap the LCP at L, find the runs of
+// ranks with LCP >= L, and re-order every run by descending position with the ordinary LSD passes over
+// (run ordinal, n-1-position).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_mql_flags(uint32_t* __restrict__ lcp, uint32_t s, uint32_t L, uint32_t* __restrict__ member)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= s) return;
+    const uint32_t raw = lcp[r];
+    const bool tie = r > 0 && raw >= L;                       // same first L characters as rank r-1
+    const bool nxt = r + 1 < s && lcp[r + 1] >= L;            // (capped or not, the test reads the same)
+    if (raw > L) lcp[r] = L;
+    member[r] = (tie || nxt) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+k_mql_compact(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ lcp,
+              const uint32_t* __restrict__ member, const uint32_t* __restrict__ off, uint32_t s, uint32_t L,
+              uint32_t* __restrict__ idx, uint32_t* __restrict__ slot, uint32_t* __restrict__ head)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= s || !member[r]) return;
+    const uint32_t j = off[r];
+    idx[j] = sa[r];
+    slot[j] = r;
+    head[j] = (r > 0 && lcp[r] >= L) ? 0u : 1u;
+}
+
+__global__ void __launch_bounds__(256)
+k_mql_keys(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ head,
+           const uint32_t* __restrict__ gid, uint32_t m, int pos_bits, uint32_t last_pos,
+           uint64_t* __restrict__ key)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    key[j] = ((uint64_t)(gid[j] + head[j]) << pos_bits) | (uint64_t)(last_pos - idx[j]);
+}
+
+__global__ void __launch_bounds__(256)
+k_scatter_slots(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ slot, uint32_t m,
+                uint32_t* __restrict__ sa)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < m) sa[slot[j]] = idx[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// --seed-mask builds (sufr_builder.rs:272-300, 350-359, 668-683; types.rs:36-200).  A suffix is ordered
+// by the characters at the mask's "care" offsets that lie inside the text; equal keys come out in
+// descending position (the merge takes the shorter suffix first, 701-712).  This is not a suffix order,
+// so it does not go through the text-streaming partition kernel: eligible positions are listed in
+// descending order and LSD-sorted on the care characters, last block of characters first.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_elig_count(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+             uint32_t* __restrict__ tilecnt)
+{
+    __shared__ uint16_t s_lut[256];
+    __shared__ uint32_t s_w[4];
+    s_lut[threadIdx.x] = glut[threadIdx.x];
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u)) cnt++;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, WAVE);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_elig_emit_desc(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+                 const uint32_t* __restrict__ tileoff, uint32_t s, uint32_t* __restrict__ idx)
+{
+    __shared__ uint16_t s_lut[256];
+    __shared__ uint32_t s_w[4];
+    s_lut[threadIdx.x] = glut[threadIdx.x];
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
+    uint32_t el = 0, cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u)) { el |= 1u << e; cnt++; }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, WAVE);
+        if ((int)lane_id() >= o) incl += t;
+    }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t r = tileoff[blockIdx.x] + incl - cnt;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) r += s_w[w];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        if (el & (1u << e)) { idx[s - 1u - r] = (uint32_t)(p0 + e); r++; }
+}
+
+// key of one block of care characters: code of text[pos + offs[k]] (0 past the end), first one highest
+__global__ void __launch_bounds__(256)
+k_mask_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+            const uint32_t* __restrict__ idx, uint32_t m, const uint32_t* __restrict__ offs, int cnt, int b,
+            uint64_t* __restrict__ key)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t p = idx[j];
+    uint64_t k = 0;
+    for (int c = 0; c < cnt; c++) {
+        const uint64_t q = p + offs[c];
+        const uint64_t code = q < n ? (uint64_t)(glut[text[q]] & 0x3ffu) : 0ull;
+        k |= code << (64 - b * (c + 1));
+    }
+    key[j] = k;
+}
+
+// LCP of the mask arm of find_lcp (272-300): equal care characters while both sides are inside the text
+__global__ void __launch_bounds__(256)
+k_mask_lcp(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t s,
+           const uint32_t* __restrict__ offs, uint32_t weight, uint32_t* __restrict__ lcp)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= s) return;
+    uint32_t c = 0;
+    if (r > 0) {
+        const uint64_t a = sa[r - 1], bpos = sa[r];
+        while (c < weight) {
+            const uint64_t qa = a + offs[c], qb = bpos + offs[c];
+            if (qa >= n || qb >= n || text[qa] != text[qb]) break;
+            c++;
+        }
+    }
+    lcp[r] = c;
+}
+
 // widen u32 results for the u64-index ABI (texts below 2^32-1 only)
 __global__ void __launch_bounds__(256)
 k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)

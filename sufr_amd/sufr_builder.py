@@ -100,7 +100,7 @@ class DeviceBuilder:
 
     def sort(self, d_text, *, is_dna=False, allow_ambiguity=False, ignore_softmask=False, raw_text=False,
              shard_index: int = 0, num_shards: int = 1, out_sa=None, out_lcp=None, num_partitions=16,
-             random_seed=42):
+             random_seed=42, max_query_len=None, seed_mask=None):
         """d_text: uint8 torch tensor on this GPU.  Returns (sa, lcp) int32-typed torch tensors holding
         u32 values (views of length num_suffixes)."""
         import torch
@@ -113,7 +113,8 @@ class DeviceBuilder:
         ns = C.c_uint64(0)
         rc = _lib.lib().sufr_hip_sort_device_u32(
             self.ctx.handle, d_text.data_ptr(), n, _flags(is_dna, allow_ambiguity, ignore_softmask, raw_text),
-            0, None, num_partitions, random_seed, shard_index, num_shards, out_sa.data_ptr(), out_lcp.data_ptr(),
+            int(max_query_len or 0), seed_mask.encode() if seed_mask is not None else None, num_partitions,
+            random_seed, shard_index, num_shards, out_sa.data_ptr(), out_lcp.data_ptr(),
             cap, C.byref(ns), C.byref(self.stats))
         self.ctx.check(rc)
         self.num_suffixes = ns.value

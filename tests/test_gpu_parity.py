@@ -24,11 +24,13 @@ def ctx():
     c.close()
 
 
-def gpu_build(ctx, raw: np.ndarray, *, is_dna=True, allow_ambiguity=False, ignore_softmask=False, width=4):
+def gpu_build(ctx, raw: np.ndarray, *, is_dna=True, allow_ambiguity=False, ignore_softmask=False, width=4,
+              max_query_len=None, seed_mask=None):
     """sufr_hip_build_u32/u64 on a raw (un-normalised) host text."""
     raw = np.ascontiguousarray(raw, dtype=np.uint8)
     args = sufr_amd.SufrBuilderArgs(text=raw, is_dna=is_dna, allow_ambiguity=allow_ambiguity,
-                                    ignore_softmask=ignore_softmask)
+                                    ignore_softmask=ignore_softmask, max_query_len=max_query_len,
+                                    seed_mask=seed_mask)
     b = sufr_amd.SufrBuilder(args, index_width=width, ctx=ctx, write=False)
     return b
 
@@ -51,7 +53,7 @@ def assert_matches_oracle(ctx, oracle, raw, *, is_dna=True, allow_ambiguity=Fals
 
 
 # ---- the reference's golden files -----------------------------------------------------------------
-GPU_GOLDEN = sorted(n for n in GOLDEN_CASES if "masked" not in n)
+GPU_GOLDEN = sorted(GOLDEN_CASES)
 
 
 @pytest.mark.parametrize("name", GPU_GOLDEN)
@@ -95,16 +97,84 @@ def test_lib_rs_inline_vectors(ctx):  # libsufr/src/lib.rs:45-140
     assert b.num_suffixes == 364
 
 
-def test_unsupported_options_fail_loudly(ctx, tmp_path):
-    with pytest.raises(sufr_amd.SufrHipError) as e:
-        sufr_amd.create(str(GOLDEN / "inputs" / "uniprot.fa"), str(tmp_path / "m.sufr"), seed_mask="10111011")
-    assert e.value.code == -6
+def test_option_errors_fail_loudly(ctx, tmp_path):
     with pytest.raises(sufr_amd.SufrHipError) as e:
         sufr_amd.create(str(GOLDEN / "inputs" / "uniprot.fa"), str(tmp_path / "m.sufr"), seed_mask="0110")
     assert e.value.code == -9 and "Invalid seed mask '0110'" in str(e.value)
+    with pytest.raises(sufr_amd.SufrHipError) as e:        # sufr_builder.rs:163-165
+        sufr_amd.create(str(GOLDEN / "inputs" / "1.fa"), str(tmp_path / "m.sufr"), max_query_len=3,
+                        seed_mask="101", is_dna=True)
+    assert "Cannot use max_query_len and seed_mask together" in str(e.value)
+    # tie order of these builds crosses prefix buckets: the sharded device entry point refuses them
+    t = torch.from_numpy(np.frombuffer(b"ACGTACGT$", dtype=np.uint8).copy()).cuda()
+    db = sufr_amd.DeviceBuilder(0)
     with pytest.raises(sufr_amd.SufrHipError) as e:
-        sufr_amd.create(str(GOLDEN / "inputs" / "1.fa"), str(tmp_path / "m.sufr"), max_query_len=3, is_dna=True)
+        db.sort(t, is_dna=True, shard_index=0, num_shards=2, max_query_len=3)
     assert e.value.code == -6
+    db.close()
+
+
+# ---- --seed-mask and --max-query-len builds -------------------------------------------------------
+def _lowent_dna(rng, n, sigma):
+    body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, sigma, size=n)]
+    return np.concatenate([body, np.frombuffer(b"$", dtype=np.uint8)])
+
+
+@pytest.mark.parametrize("mask", ["101", "1101", "10111011", "110000000011", "1" * 24 + "01",
+                                  "1" + "01" * 30])
+@pytest.mark.parametrize("n,sigma", [(5, 2), (700, 2), (5000, 4), (120_000, 3)])
+def test_seed_mask_matches_oracle(ctx, oracle, mask, n, sigma):
+    """Seed-mask builds are deterministic in the reference (ties resolved by position, 701-712)."""
+    raw = _lowent_dna(np.random.default_rng(n + len(mask)), n, sigma)
+    b = gpu_build(ctx, raw, seed_mask=mask)
+    sa, lcp, st = oracle.build(raw, is_dna=True, seed_mask=mask, threads=8)
+    assert np.array_equal(b.suffix_array, sa)
+    assert np.array_equal(b.lcp, lcp)
+
+
+def test_seed_mask_protein_and_inline_vectors(ctx, oracle):
+    d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "uniprot.fa", b"%")
+    raw = np.frombuffer(d.seq, dtype=np.uint8)
+    for mask in ["10111011", "1001", "11011"]:
+        b = gpu_build(ctx, raw, is_dna=False, seed_mask=mask)
+        sa, lcp, st = oracle.build(oracle.normalize(raw, False), seed_mask=mask, threads=8)
+        assert np.array_equal(b.suffix_array, sa) and np.array_equal(b.lcp, lcp)
+
+
+def _first_chars(norm: np.ndarray, sa: np.ndarray, L: int) -> np.ndarray:
+    """(len(sa), L) matrix of the first L characters of every listed suffix, 0 past the end."""
+    pad = np.concatenate([norm, np.zeros(L, dtype=np.uint8)])
+    return pad[sa.astype(np.int64)[:, None] + np.arange(L)[None, :]]
+
+
+@pytest.mark.parametrize("L", [1, 2, 5, 12, 20, 21, 22, 40, 300])
+@pytest.mark.parametrize("n,sigma", [(6, 1), (900, 2), (40_000, 4), (150_000, 2)])
+def test_max_query_len_canonical_form(ctx, oracle, n, sigma, L):
+    """The reference's -m builds depend on pivots and merge order (find_lcp overrides `len`, 310-314;
+    tests/test_oracle_golden.py shows it): what every such build shares is the order of the first L
+    characters and min(LCP, L).  The GPU emits the canonical member of that family: ties in descending
+    position, LCP capped at L."""
+    raw = _lowent_dna(np.random.default_rng(n * 31 + L), n, sigma)
+    b = gpu_build(ctx, raw, max_query_len=L)
+    full = gpu_build(ctx, raw)
+    sa = b.suffix_array.astype(np.int64)
+    assert np.array_equal(np.sort(sa), np.sort(full.suffix_array.astype(np.int64)))
+    assert np.array_equal(b.lcp, np.minimum(full.lcp, L))
+    tie = b.lcp >= L
+    assert np.all(sa[1:][tie[1:]] < sa[:-1][tie[1:]]), "ties must come in descending position"
+    assert np.array_equal(_first_chars(b.text, sa, min(L, 64)),
+                          _first_chars(b.text, full.suffix_array, min(L, 64)))
+    # the oracle (one member of the reference's family) agrees on both invariants
+    osa, olcp, st = oracle.build(b.text, is_dna=True, max_query_len=L, threads=8)
+    assert np.array_equal(np.minimum(olcp, L), b.lcp)
+    assert np.array_equal(_first_chars(b.text, osa, min(L, 64)), _first_chars(b.text, sa, min(L, 64)))
+
+
+def test_max_query_len_file_header(tmp_path):
+    out = tmp_path / "m.sufr"
+    sufr_amd.create(str(GOLDEN / "inputs" / "1.fa"), str(out), max_query_len=3, is_dna=True)
+    g = parse_sufr(out)
+    assert g.max_query_len == 3 and int(g.lcp.max()) <= 3
 
 
 # ---- seeded inputs against the oracle -----------------------------------------------------------------
@@ -254,6 +324,50 @@ def test_device_api_and_shards_concatenate(oracle):
         assert np.array_equal(np.concatenate(parts_sa), sa)
         assert np.array_equal(np.concatenate(parts_lcp), lcp)
     db.close()
+
+
+def test_options_on_a_5mb_genome(oracle, tmp_path):
+    """-m and -s at a size where the tie runs fill many tiles (human-like repeats, 5 Mb)."""
+    x, _ = synth.syn_human(5_000_000, seed=9)
+    raw = x.numpy()
+    db = sufr_amd.DeviceBuilder(0)
+    d_text = torch.from_numpy(raw).cuda()
+    fsa, flcp = (t.clone() for t in db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True))
+    for L in (8, 16, 33):
+        msa, mlcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, max_query_len=L)
+        assert torch.equal(mlcp, torch.clamp(flcp, max=L))
+        assert torch.equal(torch.sort(msa)[0], torch.sort(fsa)[0])
+        tie = mlcp[1:] >= L
+        assert bool(torch.all(msa[1:][tie] < msa[:-1][tie]))
+        # same first L characters rank by rank as the exact build
+        norm = torch.from_numpy(oracle.normalize(raw, True)).cuda()
+        pad = torch.cat([norm, torch.zeros(L, dtype=torch.uint8, device="cuda")])
+        pick = torch.randint(0, msa.numel(), (200_000,), device="cuda")
+        ar = torch.arange(L, device="cuda")
+        assert torch.equal(pad[(msa[pick].long()[:, None] + ar[None, :])],
+                           pad[(fsa[pick].long()[:, None] + ar[None, :])])
+    norm = oracle.normalize(raw, True)
+    for mask in ("1101", "110110110110110110110110110110011"):
+        ssa, slcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, seed_mask=mask)
+        osa, olcp, _ = oracle.build(norm, is_dna=True, seed_mask=mask, threads=8)
+        assert np.array_equal(ssa.cpu().numpy().view(np.uint32), osa)
+        assert np.array_equal(slcp.cpu().numpy().view(np.uint32), olcp)
+    db.close()
+
+
+def test_native_cli_seed_mask_and_max_query_len(tmp_path):
+    out = tmp_path / "um.sufr"
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "create", "-s", "10111011", "-o", str(out),
+                        str(GOLDEN / "inputs" / "uniprot.fa")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == (GOLDEN / "expected" / "uniprot-masked.sufr").read_bytes()
+    out = tmp_path / "m.sufr"
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "create", "-d", "-m", "2", "-o", str(out),
+                        str(GOLDEN / "inputs" / "2.fa")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    g = parse_sufr(out)
+    assert g.max_query_len == 2 and g.lcp.tolist() == np.minimum(
+        parse_sufr(GOLDEN / "expected" / "2.sufr").lcp, 2).tolist()
 
 
 # ---- BASELINE-sized property checks ---------------------------------------------------------------------
