@@ -236,6 +236,31 @@ __device__ __forceinline__ void build_tile_keys_fast(const uint8_t* s_code, Tile
     }
 }
 
+// Keys straight from the bit-packed code stream (B <= 4): the E + K codes a thread needs are at most 128
+// consecutive bits starting on a byte boundary (E * B is a multiple of 8), i.e. two unaligned 8-byte loads
+// and one 128-bit funnel shift per key -- no LDS staging, no per-character lookups, 3/8 of a byte of
+// global traffic per base.  Codes past the end of the text are 0 in the stream and never eligible.
+template <int B, int E>
+__device__ __forceinline__ void build_keys_packed_t(const uint8_t* __restrict__ packed, uint64_t pos0,
+                                                    uint32_t elig_codes, uint64_t (&key)[E], uint32_t& elig)
+{
+    static_assert(B >= 2 && B <= 4 && (E * B) % 8 == 0 && (E + 64 / B) * B <= 128, "packed window");
+    constexpr int K = 64 / B;
+    constexpr uint64_t keep = ~0ull << (64 - K * B);
+    const uint8_t* pp = packed + ((pos0 * B) >> 3);
+    const uint64_t hi = __builtin_bswap64(load_u64_unaligned(pp));
+    const uint64_t lo = __builtin_bswap64(load_u64_unaligned(pp + 8));
+    elig = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int s = e * B;
+        const uint64_t v = s ? ((hi << s) | (lo >> (64 - s))) : hi;
+        key[e] = v & keep;
+        elig |= ((elig_codes >> (uint32_t)(v >> (64 - B))) & 1u) << e;
+    }
+}
+
 // ---- generic path (any b): raw bytes staged in LDS, per-byte lookups ---------------------------------
 __device__ __forceinline__ void stage_text_tile(const uint8_t* __restrict__ text, uint64_t tile0,
                                                 uint8_t* s_text)
@@ -398,14 +423,24 @@ k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __rest
     const uint16_t* s_remap = load_remap(gremap, s_rm, kp.raw_bins);
     const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
     const uint64_t c1 = min(c0 + chunk, n);
-    uint4 nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
+    const bool use_text = !(B >= 2 && B <= 4 && kp.packed);
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (use_text) nxt = reinterpret_cast<const uint4*>(text + c0)[threadIdx.x];
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += (uint64_t)TILE * tile_stride) {
-        __syncthreads();
+        if (use_text) __syncthreads();
         const uint4 mine = nxt;
-        if (tile0 + (uint64_t)TILE * tile_stride < c1)
+        if (use_text && tile0 + (uint64_t)TILE * tile_stride < c1)
             nxt = reinterpret_cast<const uint4*>(text + tile0 + (uint64_t)TILE * tile_stride)[threadIdx.x];
         TileKeys tk;
-        tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);
+        bool from_packed = false;
+        if constexpr (B >= 2 && B <= 4) {
+            if (kp.packed) {
+                build_keys_packed_t<B, EPT>(kp.packed, tile0 + (uint64_t)threadIdx.x * EPT, kp.elig_codes, tk.key,
+                                            tk.elig);
+                from_packed = true;
+            }
+        }
+        if (!from_packed) tile_keys<B>(text, tile0, n, s_lut, s_tile, kp, tk, mine);
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             if (tk.elig & (1u << e)) {
@@ -604,8 +639,17 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
     for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
-        // stage the tile (+ halo): raw bytes -> code bytes, one 16-byte LDS store per 16 positions
-        {
+        uint64_t key[E];
+        uint32_t elig = 0;
+        bool from_packed = false;
+        if constexpr (B >= 2 && B <= 4) {
+            if (kp.packed) {
+                build_keys_packed_t<B, E>(kp.packed, tile0 + (uint64_t)threadIdx.x * E, kp.elig_codes, key, elig);
+                from_packed = true;
+            }
+        }
+        if (!from_packed) {
+            // stage the tile (+ halo): raw bytes -> code bytes, one 16-byte LDS store per 16 positions
             const uint4* src = reinterpret_cast<const uint4*>(text + tile0);
             uint4* dst = reinterpret_cast<uint4*>(s_tile);
             for (int v = threadIdx.x; v < (TILEB + HALO) / 16; v += NT) {
@@ -614,9 +658,8 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
             }
         }
         __syncthreads();
-        uint64_t key[E];
-        uint32_t elig = 0;
-        if constexpr (B > 0) {
+        if (from_packed) {
+        } else if constexpr (B > 0) {
             // whole threads (and often whole waves) sit inside runs of ineligible bytes ('N' runs are half
             // of a soft-masked genome): peek at the eligibility bits before building any key
             const uint2* own = reinterpret_cast<const uint2*>(s_tile + threadIdx.x * E);
