@@ -24,6 +24,7 @@
 namespace sufr {
 
 static constexpr int WAVE = 64;
+static_assert(RUN_TILE == (uint32_t)TILE, "run-end table granularity");
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
@@ -64,16 +65,18 @@ __device__ __forceinline__ uint64_t shfl64_up1(uint64_t v)
 // table, the eligible-suffix count and the pass-count heuristic.
 // LDS histogram is replicated 32x (bin-major) so that lanes l and l+32 share a copy and every
 // lane of a half-wave hits its own bank.  The same pass records, per 4096-byte tile, the first position
-// where a run of equal bytes ends (first_end[], the look-ahead table of k_run_fill).
+// where a run of equal bytes ends (first_end[], the RunTable of sufr_runkey.h).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n,
                      int normalize, int ignore_softmask, unsigned long long* __restrict__ ghist,
-                     uint32_t* __restrict__ first_end)
+                     uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
+                     uint64_t* __restrict__ tile_any)
 {
     __shared__ uint32_t h[256 * 32];
     __shared__ uint8_t s_first[256 + 4];
     __shared__ uint32_t s_min;
+    __shared__ uint32_t s_any[2];
     for (int i = threadIdx.x; i < 256 * 32; i += 256) h[i] = 0;
     __syncthreads();
     const uint32_t copy = threadIdx.x & 31u;
@@ -85,7 +88,7 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t p0 = tile * TILE + (uint64_t)threadIdx.x * 16;
         uint32_t by[17];
-        if (threadIdx.x == 0) s_min = 0xffffffffu;
+        if (threadIdx.x == 0) { s_min = 0xffffffffu; s_any[0] = 0; s_any[1] = 0; }
         if (p0 + 16 <= n) {
             uint4 w = *reinterpret_cast<const uint4*>(in + p0);
             uint32_t ws[4] = {w.x, w.y, w.z, w.w};
@@ -119,16 +122,31 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
         // byte after this thread's 16: the next thread's first byte, or the next tile's first byte
         if (threadIdx.x < 255) by[16] = s_first[threadIdx.x + 1];
         else by[16] = (p0 + 16 < n) ? norm(in[p0 + 16]) : 0u;
-        // first position of the tile where a run of equal bytes ends (k_run_fill's look-ahead table)
+        // first position of the tile where a run of equal bytes ends (RunTable::first_end)
         uint32_t best = 0xffffffffu;
+        uint32_t ends16 = 0;
 #pragma unroll
         for (int e = 15; e >= 0; e--) {
             uint64_t p = p0 + e;
-            if (p < n && (p == n - 1 || by[e] != by[e + 1])) best = (uint32_t)p;
+            if (p < n && (p == n - 1 || by[e] != by[e + 1])) { best = (uint32_t)p; ends16 |= 1u << e; }
         }
         if (best != 0xffffffffu) atomicMin(&s_min, best);
+        // run-end bitmap: four threads share a 64-bit word (bit i of word w <-> position 64 w + i)
+        {
+            uint64_t v = (uint64_t)ends16 << (16 * (threadIdx.x & 3u));
+            v |= shfl64_xor(v, 1);
+            v |= shfl64_xor(v, 2);
+            if ((threadIdx.x & 3u) == 0) {
+                const uint32_t j = threadIdx.x >> 2;
+                run_ends[tile * 64 + j] = v;
+                if (v) atomicOr(&s_any[j >> 5], 1u << (j & 31u));
+            }
+        }
         __syncthreads();
-        if (threadIdx.x == 0) first_end[tile] = s_min;
+        if (threadIdx.x == 0) {
+            first_end[tile] = s_min;
+            tile_any[tile] = (uint64_t)s_any[0] | ((uint64_t)s_any[1] << 32);
+        }
         __syncthreads();
     }
     {
@@ -640,6 +658,8 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
         uint64_t key[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) key[e] = 0;
         uint32_t elig = 0;
         bool from_packed = false;
         if constexpr (B >= 2 && B <= 4) {
@@ -677,24 +697,21 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
             if (acc == 0x123456789ull) out_key[0] = acc;
             continue;
         }
+        // digit lookups for all E positions first (independent LDS reads in flight together), then the
+        // ranking atomics under the eligibility mask: no load -> atomic dependency inside a branch
         uint32_t rank[E], dig[E];
-        uint32_t keep = 0;
+        uint32_t keep = elig;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            rank[e] = 0; dig[e] = 0;
-            if (elig & (1u << e)) {
-                bool mine = true;
-                if constexpr (SHARDED) {
-                    uint32_t top = digit_of(key[e], kp.top_shift, raw_mask, s_remap);
-                    mine = top >= top_lo && top < top_hi;
-                }
-                if (mine) {
-                    keep |= 1u << e;
-                    dig[e] = digit_of(key[e], shift, raw_mask, s_remap);
-                    rank[e] = atomicAdd(&s_cnt[dig[e]], 1u);
-                }
+        for (int e = 0; e < E; e++) dig[e] = digit_of(key[e], shift, raw_mask, s_remap);
+        if constexpr (SHARDED) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t top = digit_of(key[e], kp.top_shift, raw_mask, s_remap);
+                if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
             }
         }
+#pragma unroll
+        for (int e = 0; e < E; e++) rank[e] = (keep & (1u << e)) ? atomicAdd(&s_cnt[dig[e]], 1u) : 0u;
         // keys go to LDS linearly (own slots: conflict-free 16-byte stores); the suffix index is implicit
         // in the slot, so only a 4-byte (slot, digit) entry is scattered to the record's ranked position
         if (keep) {
@@ -1016,86 +1033,6 @@ k_scan_bins(const uint32_t* __restrict__ bintot, uint32_t nbins, uint32_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// Run-length array.  R[p] = min(65535, length of the run of equal bytes that starts at p), runs end at
-// the end of the text.  Genomes built with --ignore-softmask are ~50 % 'N' in runs of hundreds to
-// millions of bytes; the reference walks through them byte by byte inside find_lcp
-// (sufr_builder.rs:301-331).  With R a whole run is compared in O(1) (see make_run_key).
-//   (per 4096-byte tile, the position of its first run end comes from k_normalize_bytehist)
-//   k_run_fill:  R for every position, looking at most 16 tiles ahead (the saturation horizon)
-// ---------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256)
-k_run_fill(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ first_end,
-           uint32_t ntiles, uint16_t* __restrict__ R)
-{
-    __shared__ uint32_t s_thr[256];   // first run end inside each thread's 16 positions
-    __shared__ uint32_t s_next;       // first run end in the following tiles (within the horizon)
-    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * EPT;
-    uint32_t endpos[EPT];
-    uint32_t best = 0xffffffffu;
-    if (p0 < n) {
-        uint4 w = *reinterpret_cast<const uint4*>(text + p0);
-        uint32_t ws[5] = {w.x, w.y, w.z, w.w, (uint32_t)text[p0 + EPT]};
-#pragma unroll
-        for (int e = EPT - 1; e >= 0; e--) {
-            uint64_t p = p0 + e;
-            uint32_t a = (ws[e >> 2] >> (8 * (e & 3))) & 0xffu;
-            uint32_t b = (ws[(e + 1) >> 2] >> (8 * ((e + 1) & 3))) & 0xffu;
-            if (p < n && (p == n - 1 || a != b)) best = (uint32_t)p;
-            endpos[e] = best;           // nearest run end at or after p inside this thread's span
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < EPT; e++) endpos[e] = 0xffffffffu;
-    }
-    s_thr[threadIdx.x] = best;
-    if (threadIdx.x == 0) {
-        uint32_t nx = 0xffffffffu;
-        for (uint32_t t = blockIdx.x + 1; t < ntiles && t <= blockIdx.x + 17 && nx == 0xffffffffu; t++)
-            nx = first_end[t];
-        s_next = nx;
-    }
-    __syncthreads();
-    // nearest run end after this thread's span: exclusive suffix-min over the later threads (positions
-    // grow with the thread index, so the minimum is the nearest), then the later tiles
-    uint32_t after;
-    {
-        const int ln = (int)lane_id();
-        uint32_t v = best;                                   // inclusive suffix-min inside the wave
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            uint32_t t = __shfl_down(v, o, WAVE);
-            if (ln + o < WAVE) v = min(v, t);
-        }
-        uint32_t ex = __shfl_down(v, 1, WAVE);
-        if (ln == 63) ex = 0xffffffffu;
-        // later waves: their first-lane inclusive value is the wave minimum; s_thr was written above
-        for (int w = (threadIdx.x >> 6) + 1; w < 4 && ex == 0xffffffffu; w++) {
-            uint32_t m2 = 0xffffffffu;
-            for (int t = w * 64; t < w * 64 + 64 && m2 == 0xffffffffu; t += 1) m2 = s_thr[t];
-            ex = m2;
-        }
-        after = ex != 0xffffffffu ? ex : s_next;
-    }
-    if (p0 < n) {
-        uint16_t out[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            uint64_t p = p0 + e;
-            uint32_t en = endpos[e] != 0xffffffffu ? endpos[e] : after;
-            uint32_t len = en == 0xffffffffu ? RUN_SAT : (uint32_t)min((uint64_t)RUN_SAT, (uint64_t)en - p + 1);
-            out[e] = (uint16_t)(p < n ? len : 0);
-        }
-        uint4* dst = reinterpret_cast<uint4*>(R + p0);   // R is padded like the text
-        uint32_t pk[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) pk[q] = (uint32_t)out[2 * q] | ((uint32_t)out[2 * q + 1] << 16);
-        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_finish: wave-level finisher.  Input: records sorted by (segment, top `sorted_bits` of the key).
 // A *group* is a maximal run of records equal in (segment, those bits).  Wave t owns the window of
 // records [128t, 128t+128) and the groups whose first record lies in it.
@@ -1149,7 +1086,7 @@ __global__ void __launch_bounds__(256)
 k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
          const uint32_t* __restrict__ segdepth, uint32_t m,
-         const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ R,
+         const uint8_t* __restrict__ text, uint64_t n, RunTable R,
          const uint16_t* __restrict__ glut, KeyParams kp, int sorted_bits,
          uint32_t* __restrict__ SA, uint32_t* __restrict__ LCP,
          uint32_t* __restrict__ wl_flag, uint32_t* __restrict__ wl_head,
@@ -1394,7 +1331,7 @@ k_compact_large(const uint32_t* __restrict__ wl_flag, const uint32_t* __restrict
 // ---------------------------------------------------------------------------------------------
 // keys[e] = run key of suffix idx[e] taken segdepth[seg[e]] characters in
 __global__ void __launch_bounds__(256)
-k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ R,
+k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, RunTable R,
               const uint16_t* __restrict__ glut, const uint32_t* __restrict__ idx,
               const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth,
               const uint8_t* __restrict__ segperiod, uint32_t m, KeyParams kp, uint64_t* __restrict__ keys)

@@ -12,7 +12,21 @@
 
 namespace sufr {
 
-static constexpr uint32_t RUN_SAT = 65535u;   // saturation of the run-length array R
+static constexpr uint32_t RUN_SAT = 65535u;   // saturation of run lengths inside run keys
+static constexpr uint32_t RUN_TILE = 4096u;   // granularity of the run-end table (== TILE of the kernels)
+static constexpr uint32_t RUN_NONE = 0xffffffffu;
+
+// Run ends of the normalised text, written by the normalise pass (p is a run end iff p == n-1 or
+// text[p] != text[p+1]), at three granularities:
+//   ends[w]      bit i set: position 64 w + i is a run end                  (n / 8 bytes)
+//   tile_any[t]  bit j set: ends[64 t + j] != 0                             (8 bytes per 4096-byte tile)
+//   first_end[t] first run end of tile t, RUN_NONE if there is none         (4 bytes per tile)
+struct RunTable {
+    const uint64_t* ends;
+    const uint64_t* tile_any;
+    const uint32_t* first_end;
+    uint32_t ntiles;
+};
 
 // unaligned 8-byte little-endian load (the text buffer is padded with >= 64 zero bytes)
 SUFR_HD uint64_t load_u64_unaligned(const uint8_t* p)
@@ -113,22 +127,50 @@ SUFR_HD uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint
     return rem < RUN_SAT ? rem : RUN_SAT;
 }
 
-// pi = period assumed for the group (1 = plain runs, served by the R array).  Any pi <= the length of the
-// group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
+// min(RUN_SAT, length of the run of equal bytes that starts at q), q < n; runs end at the end of the text.
+// Genomes built with --ignore-softmask are ~50 % 'N' in runs of hundreds to millions of bytes, and the
+// reference walks through them byte by byte inside find_lcp (sufr_builder.rs:301-331).  Here a run of any
+// length costs one bitmap word, at most two more loads inside its 4 KB tile, then the tiles after it.
+SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
+{
+    uint64_t w = q >> 6;
+    uint64_t m = rt.ends[w] & (~0ull << (q & 63u));
+    if (!m) {
+        const uint64_t tile = q / RUN_TILE;
+        const uint32_t j = (uint32_t)(w & 63u);
+        const uint64_t later = j == 63u ? 0ull : (rt.tile_any[tile] & (~0ull << (j + 1u)));
+        if (later) {
+            w = (tile << 6) + (uint64_t)__builtin_ctzll(later);
+            m = rt.ends[w];
+        } else {
+            for (uint64_t t = tile + 1; t < rt.ntiles && t <= tile + 17; t++) {      // 17 tiles > RUN_SAT bytes
+                const uint32_t fe = rt.first_end[t];
+                if (fe != RUN_NONE) {
+                    const uint64_t len = (uint64_t)fe - q + 1;
+                    return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
+                }
+            }
+            return RUN_SAT;
+        }
+    }
+    const uint64_t len = (w << 6) + (uint64_t)__builtin_ctzll(m) - q + 1;
+    return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
+}
+
+// pi = period assumed for the group (1 = plain runs, served by the run-end table).  Any pi <= the length of
+// the group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
 // periodic extension up to the shorter of their two break points, and at the break the suffix whose text
 // leaves the extension is smaller iff its byte is below the byte the extension predicts there.
 SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
-                                                 const uint16_t* __restrict__ R, const uint16_t* s_lut,
+                                                 RunTable rt, const uint16_t* s_lut,
                                                  int bits, uint64_t q, uint32_t pi,
                                                  const uint8_t* __restrict__ packed = nullptr)
 {
-    // q >= pi >= 1 and q <= n.  Loads are issued unconditionally (text and R are padded) so that the two
-    // dependent rounds of memory traffic -- {c, text[q], R[q]} then {x, prediction, following words} --
-    // each go out together instead of one load per branch.
+    // q >= pi >= 1 and q <= n.  The text is padded, so loads next to q are issued without bounds checks.
     uint32_t rem = 0;
     if (pi == 1) {
-        const uint32_t cprev = text[q - 1], cq = text[q], r = R[q];
-        rem = (q < n && cq == cprev) ? r : 0u;
+        const uint32_t cprev = text[q - 1], cq = text[q];
+        if (q < n && cq == cprev) rem = run_len_at(q, rt);
     } else {
         rem = periodic_rem(text, n, q, pi);
     }

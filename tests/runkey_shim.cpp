@@ -6,7 +6,7 @@
 
 extern "C" {
 
-// R[p] = min(65535, run of equal bytes starting at p, ending at n); what k_run_first/k_run_fill compute
+// reference for run_len_at: min(65535, run of equal bytes starting at p, ending at n), one byte at a time
 void shim_run_lengths(const uint8_t* text, uint64_t n, uint16_t* R)
 {
     uint64_t p = n;
@@ -17,10 +17,41 @@ void shim_run_lengths(const uint8_t* text, uint64_t n, uint16_t* R)
         R[p] = (uint16_t)run;
     }
 }
-uint64_t shim_make_run_key(const uint8_t* text, uint64_t n, const uint16_t* R, const uint16_t* lut, int bits,
+// the run-end tables k_normalize_bytehist writes (RunTable of sufr_runkey.h); ends: 64 words per tile
+void shim_run_table(const uint8_t* text, uint64_t n, uint64_t* ends, uint64_t* tile_any, uint32_t* first_end)
+{
+    const uint64_t ntiles = (n + sufr::RUN_TILE - 1) / sufr::RUN_TILE;
+    for (uint64_t t = 0; t < ntiles; t++) {
+        first_end[t] = sufr::RUN_NONE;
+        tile_any[t] = 0;
+        for (int j = 0; j < 64; j++) ends[t * 64 + j] = 0;
+        for (uint64_t p = t * sufr::RUN_TILE; p < n && p < (t + 1) * sufr::RUN_TILE; p++)
+            if (p == n - 1 || text[p] != text[p + 1]) {
+                if (first_end[t] == sufr::RUN_NONE) first_end[t] = (uint32_t)p;
+                ends[p >> 6] |= 1ull << (p & 63);
+                tile_any[t] |= 1ull << ((p >> 6) & 63);
+            }
+    }
+}
+static sufr::RunTable shim_table(uint64_t n, const uint64_t* ends)
+{
+    // layout used by the tests: [ends: 64 words per tile][tile_any: 1 word per tile][first_end: u32 per tile]
+    const uint64_t ntiles = (n + sufr::RUN_TILE - 1) / sufr::RUN_TILE;
+    return sufr::RunTable{ends, ends + ntiles * 64, (const uint32_t*)(ends + ntiles * 65), (uint32_t)ntiles};
+}
+void shim_run_table_packed(const uint8_t* text, uint64_t n, uint64_t* buf)
+{
+    const uint64_t ntiles = (n + sufr::RUN_TILE - 1) / sufr::RUN_TILE;
+    shim_run_table(text, n, buf, buf + ntiles * 64, (uint32_t*)(buf + ntiles * 65));
+}
+uint32_t shim_run_len_at(uint64_t n, uint64_t q, const uint64_t* tab)
+{
+    return sufr::run_len_at(q, shim_table(n, tab));
+}
+uint64_t shim_make_run_key(const uint8_t* text, uint64_t n, const uint64_t* tab, const uint16_t* lut, int bits,
                            uint64_t q, uint32_t pi, const uint8_t* packed)
 {
-    return sufr::make_run_key(text, n, R, lut, bits, q, pi, packed);
+    return sufr::make_run_key(text, n, shim_table(n, tab), lut, bits, q, pi, packed);
 }
 // what k_pack_codes produces: big-endian stream of `bits`-bit codes, zero past the end
 void shim_pack_codes(const uint8_t* text, uint64_t n, const uint16_t* lut, int bits, uint8_t* packed, uint64_t cap)

@@ -23,6 +23,8 @@ def shim():
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(out), str(src)], check=True)
     L = C.CDLL(str(out))
     L.shim_run_lengths.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_run_table_packed.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.shim_run_len_at.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]; L.shim_run_len_at.restype = C.c_uint32
     L.shim_make_run_key.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]
     L.shim_pack_codes.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.shim_make_run_key.restype = C.c_uint64
@@ -79,8 +81,8 @@ def test_run_keys_are_order_preserving_and_decode_exact_lcp(shim, ti, pi):
     t = texts()[ti]
     n = t.size
     buf = np.zeros(n + PAD, dtype=np.uint8); buf[:n] = t
-    R = np.zeros(n + PAD, dtype=np.uint16)
-    shim.shim_run_lengths(buf.ctypes.data, n, R.ctypes.data)
+    R = np.zeros((n // 4096 + 2) * 66, dtype=np.uint64)     # run-end tables (RunTable of sufr_runkey.h)
+    shim.shim_run_table_packed(buf.ctypes.data, n, R.ctypes.data)
     lut, bits = make_lut(t)
     packed = np.zeros(n * bits // 8 + 128, dtype=np.uint8)
     shim.shim_pack_codes(buf.ctypes.data, n, lut.ctypes.data, bits, packed.ctypes.data, packed.size)
@@ -113,3 +115,28 @@ def test_run_keys_are_order_preserving_and_decode_exact_lcp(shim, ti, pi):
             assert com == rest, f"common: a={a} b={b} d={d} l={l} got {com} want {rest} ka={ka:016x} kb={kb:016x}"
         checked += 1
     assert checked > 200
+
+
+def test_run_len_at_matches_bytewise_runs(shim):
+    """run_len_at (run-end bitmap, per-tile summary word, per-tile first end) == the byte-at-a-time definition,
+    on runs that end inside a tile, at a tile edge, many tiles later, beyond the saturation and at the end of
+    the text (zero bytes included: the padding after the text is zero too)."""
+    rng = np.random.default_rng(3)
+    parts = []
+    for ln in [1, 2, 7, 8, 9, 63, 4095, 4096, 4097, 3, 12_000, 5, 70_000, 1, 140_000, 2, 66_000]:
+        parts.append(np.full(ln, rng.integers(0, 4), dtype=np.uint8))
+        parts.append(rng.integers(4, 9, size=int(rng.integers(1, 40)), dtype=np.uint8))
+    for tail in [np.empty(0, np.uint8), np.zeros(9000, np.uint8), np.full(5000, 65, np.uint8)]:
+        t = np.concatenate(parts + [tail])
+        # adjacent equal values across part boundaries merge into longer runs: that is fine
+        n = t.size
+        buf = np.zeros(n + PAD, dtype=np.uint8); buf[:n] = t
+        want = np.zeros(n + PAD, dtype=np.uint16)
+        shim.shim_run_lengths(buf.ctypes.data, n, want.ctypes.data)
+        tab = np.zeros((n // 4096 + 2) * 66, dtype=np.uint64)
+        shim.shim_run_table_packed(buf.ctypes.data, n, tab.ctypes.data)
+        qs = np.unique(np.concatenate([rng.integers(0, n, 30_000), np.arange(max(0, n - 70_000), n),
+                                       np.arange(0, min(n, 9000))]))
+        for q in qs.tolist():
+            got = shim.shim_run_len_at(n, q, tab.ctypes.data)
+            assert got == int(want[q]), (q, got, int(want[q]))
