@@ -421,7 +421,8 @@ k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
 // k_hist_text: per-workgroup digit histogram of the first radix pass, streaming the text.
 // Row w of `table` (layout [workgroup][bin]) counts the digit of every eligible position of workgroup
 // w's text chunk whose TOP digit lies in [top_lo, top_hi) (the shard filter used when a genome is split
-// over GPUs by prefix-bucket range; top_lo/top_hi are dense digit values).
+// over GPUs by prefix-bucket range; top_lo/top_hi are RAW digit values: the dense remap is monotone, so a
+// dense range is a raw range and the filter needs no table lookup).
 // ---------------------------------------------------------------------------------------------
 template <int B>
 __global__ void __launch_bounds__(THREADS)
@@ -462,7 +463,7 @@ k_hist_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __rest
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             if (tk.elig & (1u << e)) {
-                uint32_t top = digit_of(tk.key[e], kp.top_shift, raw_mask, s_remap);
+                uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift) & raw_mask;
                 if (top >= top_lo && top < top_hi)
                     atomicAdd(&s_cnt[digit_of(tk.key[e], shift, raw_mask, s_remap)], 1u);
             }
@@ -706,7 +707,7 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
         if constexpr (SHARDED) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint32_t top = digit_of(key[e], kp.top_shift, raw_mask, s_remap);
+                const uint32_t top = (uint32_t)(key[e] >> kp.top_shift) & raw_mask;
                 if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
             }
         }
@@ -743,6 +744,107 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
             }
             out_key[o] = s_key[slot];
             out_idx[o] = (uint32_t)(tile0 + slot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter_text_sparse: the same partition pass for texts in which at most about half of the positions
+// are suffix starts (a soft-masked genome built with --ignore-softmask is ~50 % 'N'; a shard of an N-GPU job
+// keeps 1/N of the suffixes).  The length of the run a tile contributes to a digit decides how well the
+// scattered stores fill HBM sectors, and a 4096-position tile of such a text yields only ~3 records per
+// digit.  This variant takes 8192 positions per tile (16 per thread, still one 16-byte window load), keeps
+// only the kept records in LDS -- placed directly at their ranked slot, 12 bytes each, so the staging area
+// is sized by CAP records instead of by positions and two workgroups still fit a CU -- and falls back to
+// two half-tile flushes where a tile holds more than CAP suffix starts.
+// ---------------------------------------------------------------------------------------------
+static constexpr int SPARSE_NT = 512, SPARSE_E = 16, SPARSE_CAP = 4864;
+
+template <int B, bool SHARDED>
+__global__ void __launch_bounds__(SPARSE_NT)
+k_scatter_text_sparse(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
+                      uint32_t top_lo, uint32_t top_hi, const uint32_t* __restrict__ table,
+                      const uint32_t* __restrict__ binbase, uint64_t* __restrict__ out_key,
+                      uint32_t* __restrict__ out_idx)
+{
+    constexpr int NT = SPARSE_NT, E = SPARSE_E, CAP = SPARSE_CAP;
+    constexpr int TILEB = NT * E;                          // 8192 positions: 13 bits in the staged entry
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t NB = kp.nbins;
+    const uint32_t NBa = (NB + 3u) & ~3u;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_gbase = s_cnt + NBa;
+    uint32_t* s_gdelta = s_gbase + NBa;
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);      // CAP, in digit order
+    uint32_t* s_pv = reinterpret_cast<uint32_t*>(s_key + CAP);          // CAP: digit << 13 | position in tile
+    uint32_t* s_misc = s_pv + CAP;                                       // 32
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 32);           // raw_bins
+
+    const uint32_t raw_mask = kp.raw_bins - 1;
+    const uint32_t* row = table + (size_t)blockIdx.x * NB;
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
+    const uint16_t* s_remap = nullptr;
+    if (gremap) {
+        for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += NT) s_rm[i] = gremap[i];
+        s_remap = s_rm;
+    }
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t c1 = min(c0 + chunk, n);
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
+        __syncthreads();                                   // the previous copy-out is done with the staging area
+        for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
+        uint64_t key[E];
+        uint32_t keep;
+        build_keys_packed_t<B, E>(kp.packed, tile0 + (uint64_t)threadIdx.x * E, kp.elig_codes, key, keep);
+        uint32_t dig[E], rank[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) dig[e] = digit_of(key[e], shift, raw_mask, s_remap);
+        if constexpr (SHARDED) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t top = (uint32_t)(key[e] >> kp.top_shift) & raw_mask;
+                if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
+            }
+        }
+        // kept records of the whole tile: one flush if they fit the staging area, else two half tiles
+        {
+            uint32_t c = (uint32_t)__popc(keep);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, WAVE);
+            if (lane_id() == 0) s_misc[8 + (threadIdx.x >> 6)] = c;
+        }
+        __syncthreads();
+        uint32_t kept = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) kept += s_misc[8 + w];
+        const int halves = kept > (uint32_t)CAP ? 2 : 1;
+        for (int h = 0; h < halves; h++) {
+            const uint32_t mask = halves == 1 ? keep : (keep & (h ? 0xff00u : 0x00ffu));
+            if (h) {
+                __syncthreads();                           // first half copied out
+                for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
+                __syncthreads();
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) rank[e] = (mask & (1u << e)) ? atomicAdd(&s_cnt[dig[e]], 1u) : 0u;
+            __syncthreads();
+            block_scan_bins_t<NT>(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
+            const uint32_t total = s_misc[24];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (mask & (1u << e)) {
+                    const uint32_t pos = s_cnt[dig[e]] + rank[e];
+                    s_key[pos] = key[e];
+                    s_pv[pos] = (dig[e] << 13) | (uint32_t)(threadIdx.x * E + e);
+                }
+            }
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < total; j += NT) {
+                const uint32_t v = s_pv[j];
+                const uint32_t o = j + s_gdelta[v >> 13];
+                out_key[o] = s_key[j];
+                out_idx[o] = (uint32_t)(tile0 + (v & 0x1fffu));
+            }
         }
     }
 }
