@@ -233,7 +233,8 @@ def main():
                        "parallelism": f"prefix-bucket shards x{world}", "bits_per_char": st["bits_per_char"],
                        "radix_passes": st["num_passes"], "digit_bits": st["digit_bits"],
                        "levels": st["num_levels"], "deep_records": st["deep_records"]},
-            "roofline": {"kernel": "k_scatter_text (radix partition, first pass)", "bound": "hbm",
+            "roofline": {"kernel": ("k_scatter_text_sparse" if st.get("partition_variant") else "k_scatter_text")
+                         + " (radix partition, first pass)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes(args.workload) if world == 1 and not args.bases else None,

@@ -27,6 +27,7 @@ class Stats(C.Structure):
         ("digit_bits", C.c_uint32), ("num_passes", C.c_uint32), ("num_levels", C.c_uint32),
         ("num_large_groups", C.c_uint64), ("deep_records", C.c_uint64),
         ("top_lo", C.c_uint32), ("top_hi", C.c_uint32), ("partition_workgroups", C.c_uint32),
+        ("partition_variant", C.c_uint32),
         ("ms_total", C.c_float), ("ms_normalize", C.c_float), ("ms_hist_text", C.c_float),
         ("ms_partition", C.c_float), ("ms_passes", C.c_float), ("ms_finish", C.c_float),
         ("ms_deep", C.c_float),

@@ -797,8 +797,6 @@ k_scatter_text_sparse(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams
         uint32_t keep;
         build_keys_packed_t<B, E>(kp.packed, tile0 + (uint64_t)threadIdx.x * E, kp.elig_codes, key, keep);
         uint32_t dig[E], rank[E];
-#pragma unroll
-        for (int e = 0; e < E; e++) dig[e] = digit_of(key[e], shift, raw_mask, s_remap);
         if constexpr (SHARDED) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
@@ -806,6 +804,9 @@ k_scatter_text_sparse(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams
                 if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
             }
         }
+        // digit lookups only for kept positions (all issued before the first is used)
+#pragma unroll
+        for (int e = 0; e < E; e++) dig[e] = (keep & (1u << e)) ? digit_of(key[e], shift, raw_mask, s_remap) : 0u;
         // kept records of the whole tile: one flush if they fit the staging area, else two half tiles
         {
             uint32_t c = (uint32_t)__popc(keep);
