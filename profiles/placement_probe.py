@@ -1,5 +1,6 @@
 """Does HBM bandwidth depend on where an allocation lands?  Streaming copy of 12 GB between freshly
-allocated buffers, re-allocated every round (python profiles/placement_probe.py)."""
+allocated buffers, re-allocated every round, with the destination shifted by a few offsets inside its
+allocation (python profiles/placement_probe.py)."""
 import torch
 
 def timed(fn, reps=3):
@@ -12,17 +13,20 @@ def timed(fn, reps=3):
     return best
 
 GB = 1 << 30
-keep = []
-for round_ in range(10):
-    src = torch.empty(12 * GB, dtype=torch.uint8, device="cuda")
-    dst = torch.empty(12 * GB, dtype=torch.uint8, device="cuda")
+N = 12 * GB
+SKEWS = [0, 4 << 10, 64 << 10, 256 << 10, (1 << 20) + (4 << 10), (2 << 20), (3 << 20) + (192 << 10), 16 << 20, (64 << 20) + (68 << 10)]
+for round_ in range(8):
+    src = torch.empty(N + (128 << 20), dtype=torch.uint8, device="cuda")
+    dst = torch.empty(N + (128 << 20), dtype=torch.uint8, device="cuda")
     src.zero_(); dst.zero_()
-    t_copy = timed(lambda: dst.copy_(src))
-    t_fill = timed(lambda: dst.fill_(1))
-    t_read = timed(lambda: src.view(torch.int64).sum())
-    print(f"round {round_}: src {src.data_ptr():#x} dst {dst.data_ptr():#x} copy {24 * GB / t_copy / 1e6:.0f} GB/s "
-          f"fill {12 * GB / t_fill / 1e6:.0f} GB/s read {12 * GB / t_read / 1e6:.0f} GB/s", flush=True)
-    if round_ % 3 == 2:
-        keep.append(torch.empty(7 * GB, dtype=torch.uint8, device="cuda"))   # shift later placements
-    del src, dst
+    res = []
+    for sk in SKEWS:
+        d = dst[sk:sk + N]
+        t = timed(lambda: d.copy_(src[:N]))
+        res.append(2 * N / t / 1e6)
+    t_fill = timed(lambda: dst[:N].fill_(1))
+    t_read = timed(lambda: src[:N].view(torch.int64).sum())
+    print(f"round {round_}: copy GB/s by dst skew " + " ".join(f"{r:.0f}" for r in res) +
+          f" | fill {N / t_fill / 1e6:.0f} read {N / t_read / 1e6:.0f}", flush=True)
+    del src, dst, d
     torch.cuda.empty_cache()
