@@ -187,6 +187,22 @@ def test_random_dna_sizes(ctx, oracle, n):
     assert_matches_oracle(ctx, oracle, raw)
 
 
+def test_sparse_partition_kernel_both_flush_modes(ctx, oracle):
+    """At most ~55 % suffix starts selects k_scatter_text_sparse (8192-position tiles).  Dense stretches
+    overflow its record-sized staging area and are flushed as two half tiles; N-rich stretches fit in one."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = [acgt[rng.integers(0, 4, size=70_000)]]                         # dense: two flushes per tile
+    mixed = acgt[rng.integers(0, 4, size=150_000)]
+    for st in range(0, mixed.size, 900):                                     # ~45 % kept: one flush per tile
+        mixed[st:st + int(rng.integers(300, 700))] = ord("N")
+    parts += [mixed, np.full(60_000, ord("N"), dtype=np.uint8), acgt[rng.integers(0, 4, size=9_000)]]
+    raw = np.concatenate(parts + [np.frombuffer(b"$", dtype=np.uint8)])
+    b = assert_matches_oracle(ctx, oracle, raw)
+    assert b.num_suffixes <= 0.55 * raw.size
+    assert b.stats.partition_variant == 1
+
+
 def test_empty_text(ctx):
     b = gpu_build(ctx, np.empty(0, dtype=np.uint8))
     assert b.num_suffixes == 0
