@@ -386,6 +386,112 @@ def test_native_cli_seed_mask_and_max_query_len(tmp_path):
         parse_sufr(GOLDEN / "expected" / "2.sufr").lcp, 2).tolist()
 
 
+# ---- randomised differential test --------------------------------------------------------------------
+def _fuzz_text(rng):
+    """A small text with a random alphabet, repeat structure, case mix and terminator."""
+    n = int(rng.choice([1, 2, 3, 5, 17, 64, 129, 700, 4097, 9000]) + rng.integers(0, 40))
+    kind = int(rng.integers(0, 5))
+    if kind == 0:      # DNA-like with IUPAC, N runs and lowercase
+        alpha = np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8)
+        p = np.array([20, 20, 20, 20, 6, 3, 3, 3, 3, 1, 0.5, 0.5]); p = p / p.sum()
+        t = alpha[rng.choice(alpha.size, size=n, p=p)]
+    elif kind == 1:    # tiny alphabet: long runs and deep ties
+        sigma = int(rng.integers(1, 4))
+        t = np.frombuffer(b"ACG", dtype=np.uint8)[rng.integers(0, sigma, size=n)]
+    elif kind == 2:    # periodic with mutations
+        unit = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(1, 9)))]
+        t = np.resize(unit, n).copy()
+        hit = rng.random(n) < 0.01
+        t[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+    elif kind == 3:    # protein-like
+        alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYX", dtype=np.uint8)
+        t = alpha[rng.integers(0, alpha.size, size=n)]
+    else:              # arbitrary bytes from a random subset
+        sub = rng.choice(256, size=int(rng.integers(2, 40)), replace=False).astype(np.uint8)
+        t = sub[rng.integers(0, sub.size, size=n)]
+    t = t.copy()
+    if n > 40 and rng.random() < 0.5:      # a copied block: long common prefixes
+        ln = int(rng.integers(5, n // 3)); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+        t[b:b + ln] = t[a:a + ln].copy()
+    if n > 10 and rng.random() < 0.5:      # several sequences
+        for c in rng.integers(1, n - 1, size=int(rng.integers(1, 4))):
+            t[c] = ord("%")
+    if rng.random() < 0.8:
+        t = np.concatenate([t, np.frombuffer(b"$", dtype=np.uint8)])
+    return t
+
+
+@pytest.mark.parametrize("block", range(12))
+def test_fuzz_small_texts_against_oracle(ctx, oracle, block):
+    rng = np.random.default_rng(1000 + block)
+    for case in range(60):
+        raw = _fuzz_text(rng)
+        is_dna = bool(rng.random() < 0.6)
+        amb = bool(rng.random() < 0.3)
+        soft = bool(rng.random() < 0.5)
+        if amb:
+            raw = _break_long_n_runs(raw, soft)
+        mask = None
+        if rng.random() < 0.15:
+            ml = int(rng.integers(3, 12))
+            mask = "1" + "".join(rng.choice(["0", "1"], size=ml - 2)) + "1"
+            if "0" not in mask or not mask.startswith("1") or "10" not in mask and "0" in mask:
+                mask = "1101"
+            i = mask.index("0")
+            mask = "1" * i + mask[i:]
+        norm = oracle.normalize(np.ascontiguousarray(raw, dtype=np.uint8), soft)
+        what = dict(is_dna=is_dna, allow_ambiguity=amb)
+        try:
+            b = gpu_build(ctx, raw, ignore_softmask=soft, seed_mask=mask, **what)
+        except sufr_amd.SufrHipError as e:
+            raise AssertionError(f"block {block} case {case}: {e} (n={raw.size}, {what}, mask={mask})")
+        if norm.size >= 4:
+            try:
+                sa, lcp, st = oracle.build(norm, seed_mask=mask, threads=4, **what)
+            except RuntimeError:       # fewer eligible positions than the pivots the reference wants to draw
+                if mask is not None:   # (it would spin in select_pivots, 786-800): only the witness remains
+                    continue
+                sa, lcp = naive_sa_lcp(norm, is_dna, amb)
+        elif mask is None:
+            sa, lcp = naive_sa_lcp(norm, is_dna, amb)
+        else:
+            continue
+        ctxt = f"block {block} case {case} n={raw.size} {what} soft={soft} mask={mask}"
+        assert np.array_equal(b.text, norm), ctxt
+        assert np.array_equal(b.suffix_array, sa), ctxt
+        assert np.array_equal(b.lcp, lcp), ctxt
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_fuzz_shards_concatenate_to_the_single_build(block):
+    """Any number of prefix-bucket shards (empty ones included) concatenates to the one-GPU arrays once the
+    first LCP of every non-empty shard but the first is stitched (sufr_builder.rs:893-902)."""
+    rng = np.random.default_rng(5000 + block)
+    db = sufr_amd.DeviceBuilder(0)
+    for case in range(25):
+        raw = _fuzz_text(rng)
+        is_dna = bool(rng.random() < 0.6)
+        soft = bool(rng.random() < 0.5)
+        d_text = torch.from_numpy(raw).cuda()
+        fsa, flcp = db.sort(d_text, is_dna=is_dna, ignore_softmask=soft, raw_text=True)
+        fsa = fsa.cpu().numpy().view(np.uint32).copy(); flcp = flcp.cpu().numpy().view(np.uint32).copy()
+        norm = sufr_amd.normalize(raw, soft)
+        shards = int(rng.choice([2, 3, 5, 8]))
+        parts_sa, parts_lcp = [], []
+        for r in range(shards):
+            psa, plcp = db.sort(d_text, is_dna=is_dna, ignore_softmask=soft, raw_text=True, shard_index=r,
+                                num_shards=shards)
+            psa = psa.cpu().numpy().view(np.uint32).copy(); plcp = plcp.cpu().numpy().view(np.uint32).copy()
+            prev = next((p for p in reversed(parts_sa) if p.size), None)
+            if prev is not None and psa.size:
+                plcp[0] = sufr_amd.lcp_pair(norm, int(prev[-1]), int(psa[0]))
+            parts_sa.append(psa); parts_lcp.append(plcp)
+        ctxt = f"block {block} case {case} n={raw.size} shards={shards} dna={is_dna} soft={soft}"
+        assert np.array_equal(np.concatenate(parts_sa), fsa), ctxt
+        assert np.array_equal(np.concatenate(parts_lcp), flcp), ctxt
+    db.close()
+
+
 # ---- BASELINE-sized property checks ---------------------------------------------------------------------
 def test_elegans_config_c3_properties(oracle):
     """BASELINE config C3 size (100 Mb, 7 sequences): too big for the oracle in seconds, so check the
