@@ -76,6 +76,10 @@ typedef struct sufr_hip_stats {
     float ms_passes;            /* remaining LSD passes */
     float ms_finish;            /* k_finish of the top level */
     float ms_deep;              /* all deeper levels */
+    /* host phases of sufr_hip_create_file (seconds; 0 from the other entry points) */
+    float host_read_s;          /* sequence file -> text */
+    float host_build_s;         /* H2D + device build (+ first-use allocations) */
+    float host_write_s;         /* D2H + .sufr written */
 } sufr_hip_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

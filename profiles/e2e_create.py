@@ -63,7 +63,7 @@ if wl == "elegans" or os.environ.get("SUFR_E2E_CLI_HUMAN"):
                 f.write(lines.tobytes())
             if seq.size > full:
                 f.write(seq[full:].tobytes() + b"\n")
-    cmd = [str(sufr_amd.CLI_PATH), "--log", "info", "create", "--dna", "-n", str(parts), "-o", str(tmp / f"syn_{wl}.sufr"), str(fa)]
+    cmd = [str(sufr_amd.CLI_PATH), "--log", "debug", "create", "--dna", "-n", str(parts), "-o", str(tmp / f"syn_{wl}.sufr"), str(fa)]
     if flags.get("ignore_softmask"):
         cmd.insert(5, "--ignore-softmask")
     t0 = time.perf_counter()
@@ -72,7 +72,7 @@ if wl == "elegans" or os.environ.get("SUFR_E2E_CLI_HUMAN"):
     out["sufr_create"] = {"seconds": dt, "suffixes_per_s": s / dt, "returncode": r.returncode,
                           "fasta_bytes": fa.stat().st_size,
                           "sufr_bytes": (tmp / f"syn_{wl}.sufr").stat().st_size if r.returncode == 0 else 0,
-                          "log": r.stdout.strip().splitlines()[-4:], "stderr": r.stderr[-300:]}
+                          "log": r.stdout.strip().splitlines()[-5:], "stderr": r.stderr[-300:]}
     for p in (fa, tmp / f"syn_{wl}.sufr"):
         try:
             p.unlink()

@@ -30,7 +30,8 @@ class Stats(C.Structure):
         ("partition_variant", C.c_uint32),
         ("ms_total", C.c_float), ("ms_normalize", C.c_float), ("ms_hist_text", C.c_float),
         ("ms_partition", C.c_float), ("ms_passes", C.c_float), ("ms_finish", C.c_float),
-        ("ms_deep", C.c_float),
+        ("ms_deep", C.c_float), ("host_read_s", C.c_float), ("host_build_s", C.c_float),
+        ("host_write_s", C.c_float),
     ]
 
     def as_dict(self):

@@ -21,6 +21,7 @@ struct Log {
     int level = 0;  // 0 off, 1 info, 2 debug
     FILE* out = stdout;
     void info(const std::string& s) const { if (level >= 1) { fprintf(out, "[INFO  sufr] %s\n", s.c_str()); fflush(out); } }
+    void debug(const std::string& s) const { if (level >= 2) { fprintf(out, "[DEBUG sufr] %s\n", s.c_str()); fflush(out); } }
 };
 
 std::string with_commas(uint64_t v)
@@ -139,6 +140,9 @@ int main(int argc, char** argv)
     uint64_t bytes = stat(path, &sb) == 0 ? (uint64_t)sb.st_size : 0;
     snprintf(buf, sizeof buf, "Wrote %s byte%s to '%s' in %.3fs", with_commas(bytes).c_str(), bytes == 1 ? "" : "s", path, secs);
     log.info(buf);
+    snprintf(buf, sizeof buf, "host phases: read %.3fs, H2D + build %.3fs, D2H + write %.3fs", st.host_read_s,
+             st.host_build_s, st.host_write_s);
+    log.debug(buf);
     sufr_hip_destroy(ctx);
     if (log.out != stdout) fclose(log.out);
     return 0;

@@ -15,8 +15,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../include/sufr_hip.h"
 
@@ -82,9 +87,200 @@ struct Out {
     void u64(uint64_t v) { uint8_t b[8]; le64(b, v); raw(b, 8); }   // usize_to_bytes, util.rs:138-152
 };
 
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+unsigned host_threads(unsigned cap)
+{
+    unsigned h = std::thread::hardware_concurrency();
+    if (h == 0) h = 4;
+    return h < cap ? h : cap;
+}
+
+// ---- multi-threaded FASTA reader (same result as the serial loop in sufr_read_sequence_file) ---------------
+// The file is cut into line-aligned slices; a first sweep counts, per slice, the sequence bytes before its
+// first header and after every header; prefix sums give every slice its place in the output; a second sweep
+// copies the sequence bytes.  A line is a header iff it starts with '>' (util.rs:55-79 via needletail).
+struct FaSlice {
+    const uint8_t* b = nullptr;
+    const uint8_t* e = nullptr;
+    uint64_t lead = 0;                       // sequence bytes before the slice's first header
+    std::vector<const uint8_t*> hdr;         // header lines (pointing at '>')
+    std::vector<uint64_t> after;             // sequence bytes after each header, inside the slice
+};
+
+inline uint64_t line_payload(const uint8_t* p, const uint8_t* q)      // bytes of [p,q) that are not '\r'
+{
+    uint64_t c = (uint64_t)(q - p);
+    while (p < q) {
+        const uint8_t* r = (const uint8_t*)memchr(p, '\r', (size_t)(q - p));
+        if (!r) break;
+        c--; p = r + 1;
+    }
+    return c;
+}
+
+inline uint8_t* copy_payload(uint8_t* dst, const uint8_t* p, const uint8_t* q)
+{
+    while (p < q) {
+        const uint8_t* r = (const uint8_t*)memchr(p, '\r', (size_t)(q - p));
+        const uint8_t* stop = r ? r : q;
+        memcpy(dst, p, (size_t)(stop - p));
+        dst += stop - p;
+        p = r ? r + 1 : q;
+    }
+    return dst;
+}
+
+void fasta_parallel(const uint8_t* p, const uint8_t* end, uint8_t delimiter, unsigned T, uint8_t* out,
+                    uint64_t& out_len, std::vector<uint64_t>& starts, std::vector<std::string>& names)
+{
+    std::vector<FaSlice> sl(T);
+    const uint64_t total = (uint64_t)(end - p);
+    for (unsigned t = 0; t < T; t++) {
+        const uint8_t* b = p + total * t / T;
+        if (t > 0) {                                      // move to the start of the next line
+            b = find_byte(b - 1, end, '\n');
+            b = b < end ? b + 1 : end;
+        }
+        sl[t].b = b;
+        if (t > 0) sl[t - 1].e = b;
+    }
+    sl[T - 1].e = end;
+    auto sweep = [&](unsigned t) {
+        FaSlice& s = sl[t];
+        uint64_t* cur = &s.lead;
+        for (const uint8_t* q = s.b; q < s.e;) {
+            const uint8_t* le = find_byte(q, s.e, '\n');
+            if (*q == '>') {
+                s.hdr.push_back(q);
+                s.after.push_back(0);
+                cur = &s.after.back();
+            } else {
+                *cur += line_payload(q, le);
+            }
+            q = le < s.e ? le + 1 : s.e;
+            if (!s.after.empty()) cur = &s.after.back();   // the vector may have moved
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back(sweep, t);
+        for (auto& x : th) x.join();
+    }
+    // place of every slice in the output, and the global index of its first header
+    std::vector<uint64_t> at(T), first_rec(T);
+    uint64_t pos = 0, rec = 0;
+    for (unsigned t = 0; t < T; t++) {
+        at[t] = pos; first_rec[t] = rec;
+        pos += sl[t].lead;
+        for (size_t h = 0; h < sl[t].hdr.size(); h++) {
+            if (rec > 0) pos++;                            // delimiter before every record but the first
+            pos += sl[t].after[h];
+            rec++;
+        }
+    }
+    out_len = pos;
+    starts.assign(rec, 0);
+    names.assign(rec, std::string());
+    auto fill = [&](unsigned t) {
+        const FaSlice& s = sl[t];
+        uint8_t* dst = out + at[t];
+        uint64_t r = first_rec[t];
+        for (const uint8_t* q = s.b; q < s.e;) {
+            const uint8_t* le = find_byte(q, s.e, '\n');
+            if (*q == '>') {
+                if (r > 0) *dst++ = delimiter;             // util.rs:62-64
+                starts[r] = (uint64_t)(dst - out);         // util.rs:67
+                const uint8_t* hb = q + 1;
+                const uint8_t* he = le;
+                if (he > hb && he[-1] == '\r') he--;
+                const uint8_t* a = hb;
+                while (a < he && (*a == ' ' || *a == '\t')) a++;
+                const uint8_t* b = a;
+                while (b < he && *b != ' ' && *b != '\t') b++;
+                names[r] = b > a ? std::string((const char*)a, (size_t)(b - a)) : std::to_string(r + 2);
+                r++;
+            } else {
+                dst = copy_payload(dst, q, le);
+            }
+            q = le < s.e ? le + 1 : s.e;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back(fill, t);
+    for (auto& x : th) x.join();
+}
+
+// ---- .sufr v6 header and tail (SufrBuilder::write, sufr_builder.rs:826-867, 909) -----------------------------
+struct SufrLayout {
+    std::vector<uint8_t> head;   // everything before the text, section offsets filled in
+    std::vector<uint8_t> tail;   // bincode Vec<String> of the sequence names
+    uint64_t text_pos = 0, sa_pos = 0, lcp_pos = 0, tail_pos = 0;
+};
+
+void push64(std::vector<uint8_t>& v, uint64_t x) { for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+
+SufrLayout sufr_layout(int is_dna, int allow_ambiguity, int ignore_softmask, uint64_t text_len, int index_width,
+                       uint64_t num_suffixes, int has_max_query_len, uint64_t max_query_len, const char* seed_mask,
+                       const uint64_t* sequence_starts, uint64_t num_sequences, const char* const* sequence_names)
+{
+    SufrLayout L;
+    std::vector<uint8_t>& h = L.head;
+    h.push_back(SUFR_OUTFILE_VERSION); h.push_back((uint8_t)(is_dna != 0));
+    h.push_back((uint8_t)(allow_ambiguity != 0)); h.push_back((uint8_t)(ignore_softmask != 0));
+    push64(h, text_len);
+    const size_t locs = h.size();
+    push64(h, 0); push64(h, 0); push64(h, 0);
+    push64(h, num_suffixes);
+    push64(h, (!seed_mask && has_max_query_len) ? max_query_len : 0);
+    push64(h, num_sequences);
+    for (uint64_t i = 0; i < num_sequences; i++) {          // stored T-wide (857)
+        const uint64_t v = sequence_starts[i];
+        for (int k = 0; k < index_width; k++) h.push_back((uint8_t)(v >> (8 * k)));
+    }
+    if (seed_mask) {
+        const size_t ml = strlen(seed_mask);
+        push64(h, ml);
+        for (size_t i = 0; i < ml; i++) h.push_back(seed_mask[i] == '1');
+    } else {
+        push64(h, 0);
+    }
+    L.text_pos = h.size();
+    L.sa_pos = L.text_pos + text_len;
+    L.lcp_pos = L.sa_pos + num_suffixes * (uint64_t)index_width;
+    L.tail_pos = L.lcp_pos + num_suffixes * (uint64_t)index_width;
+    const uint64_t p3[3] = {L.text_pos, L.sa_pos, L.lcp_pos};
+    for (int k = 0; k < 3; k++) le64(h.data() + locs + 8 * k, p3[k]);
+    push64(L.tail, num_sequences);                          // bincode 1.x Vec<String>
+    for (uint64_t i = 0; i < num_sequences; i++) {
+        const size_t l = strlen(sequence_names[i]);
+        push64(L.tail, l);
+        L.tail.insert(L.tail.end(), sequence_names[i], sequence_names[i] + l);
+    }
+    return L;
+}
+
+bool pwrite_all(int fd, const void* buf, size_t len, uint64_t off)
+{
+    const uint8_t* p = (const uint8_t*)buf;
+    while (len) {
+        ssize_t w = pwrite(fd, p, len, (off_t)off);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; off += (uint64_t)w; len -= (size_t)w;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg);  // sufr_capi.inc
+extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t flags,
+                                        uint64_t max_query_len, const char* seed_mask, uint64_t* num_suffixes,
+                                        sufr_hip_stats* stats, int* device, const void** d_text,
+                                        const void** d_sa, const void** d_lcp);           // sufr_capi.inc
 
 extern "C" {
 
@@ -134,6 +330,31 @@ int sufr_read_sequence_file(const char* path, uint8_t delimiter, sufr_sequence_d
         return SUFR_HIP_E_IO;
     }
     const bool fastq = *p == '@';
+    const unsigned T = host_threads(32);
+    if (!fastq && T > 1 && (size_t)(end - p) >= ((size_t)32 << 20) && !getenv("SUFR_SERIAL_READER")) {
+        std::vector<uint64_t> pstarts;
+        std::vector<std::string> pnames;
+        uint8_t* buf = (uint8_t*)malloc((size_t)(end - p) + 2);
+        if (!buf) { put_err(err, errlen, "out of memory"); return SUFR_HIP_E_NOMEM; }
+        uint64_t len = 0;
+        fasta_parallel(p, end, delimiter, T, buf, len, pstarts, pnames);
+        buf[len++] = SUFR_SENTINEL_CHARACTER;                        // util.rs:83
+        out->seq = buf;
+        out->seq_len = len;
+        out->num_sequences = pstarts.size();
+        out->start_positions = (uint64_t*)malloc(sizeof(uint64_t) * (pstarts.size() ? pstarts.size() : 1));
+        out->sequence_names = (char**)calloc(pstarts.size() ? pstarts.size() : 1, sizeof(char*));
+        if (!out->start_positions || !out->sequence_names) {
+            sufr_sequence_data_free(out);
+            put_err(err, errlen, "out of memory");
+            return SUFR_HIP_E_NOMEM;
+        }
+        for (size_t i = 0; i < pstarts.size(); i++) {
+            out->start_positions[i] = pstarts[i];
+            out->sequence_names[i] = strdup(pnames[i].c_str());
+        }
+        return 0;
+    }
     std::vector<uint8_t> seq;
     seq.reserve(fv.size + 1);
     std::vector<uint64_t> starts;
@@ -210,48 +431,19 @@ int sufr_write_file(const char* path, int is_dna, int allow_ambiguity, int ignor
                     const char* const* sequence_names, char* err, size_t errlen)
 {
     if (!path || (index_width != 4 && index_width != 8)) return SUFR_HIP_E_INVALID;
+    const SufrLayout L = sufr_layout(is_dna, allow_ambiguity, ignore_softmask, text_len, index_width, num_suffixes,
+                                     has_max_query_len, max_query_len, seed_mask, sequence_starts, num_sequences,
+                                     sequence_names);
     Out o;
     o.f = fopen(path, "wb");
     if (!o.f) { put_err(err, errlen, std::string(path) + ": " + strerror(errno)); return SUFR_HIP_E_IO; }
     static char iobuf[1 << 20];
     setvbuf(o.f, iobuf, _IOFBF, sizeof iobuf);
-    const uint8_t head[4] = {SUFR_OUTFILE_VERSION, (uint8_t)(is_dna != 0), (uint8_t)(allow_ambiguity != 0),
-                             (uint8_t)(ignore_softmask != 0)};
-    o.raw(head, 4);
-    o.u64(text_len);
-    const uint64_t locs = o.pos;          // text_pos, sa_pos, lcp_pos: patched at the end
-    o.u64(0); o.u64(0); o.u64(0);
-    o.u64(num_suffixes);
-    o.u64((!seed_mask && has_max_query_len) ? max_query_len : 0);
-    o.u64(num_sequences);
-    for (uint64_t i = 0; i < num_sequences; i++) {          // stored T-wide
-        if (index_width == 4) { uint32_t v = (uint32_t)sequence_starts[i]; o.raw(&v, 4); }
-        else { uint64_t v = sequence_starts[i]; o.raw(&v, 8); }
-    }
-    if (seed_mask) {
-        size_t ml = strlen(seed_mask);
-        o.u64(ml);
-        std::vector<uint8_t> mb(ml);
-        for (size_t i = 0; i < ml; i++) mb[i] = seed_mask[i] == '1';
-        o.raw(mb.data(), ml);
-    } else {
-        o.u64(0);
-    }
-    const uint64_t text_pos = o.pos;
+    o.raw(L.head.data(), L.head.size());
     o.raw(norm_text, text_len);
-    const uint64_t sa_pos = o.pos;
     o.raw(sa, (size_t)(num_suffixes * (uint64_t)index_width));
-    const uint64_t lcp_pos = o.pos;
     o.raw(lcp, (size_t)(num_suffixes * (uint64_t)index_width));
-    // bincode 1.x Vec<String>: u64 count, then u64 length + UTF-8 bytes per name
-    o.u64(num_sequences);
-    for (uint64_t i = 0; i < num_sequences; i++) {
-        size_t l = strlen(sequence_names[i]);
-        o.u64(l);
-        o.raw(sequence_names[i], l);
-    }
-    if (fseeko(o.f, (off_t)locs, SEEK_SET) != 0) o.bad = true;
-    o.u64(text_pos); o.u64(sa_pos); o.u64(lcp_pos);
+    o.raw(L.tail.data(), L.tail.size());
     if (fclose(o.f) != 0) o.bad = true;
     if (o.bad) { put_err(err, errlen, std::string(path) + ": write failed"); return SUFR_HIP_E_IO; }
     return 0;
@@ -263,9 +455,11 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
     if (!ctx || !a || !a->input) return SUFR_HIP_E_INVALID;
     char err[512] = {0};
     sufr_sequence_data sd;
+    const double t_start = now_s();
     int rc = sufr_read_sequence_file(a->input, a->sequence_delimiter ? a->sequence_delimiter : (uint8_t)'%', &sd,
                                      err, sizeof err);
     if (rc != 0) { sufr_hip_set_error_(ctx, err); return rc; }
+    const double t_read = now_s();
     // default output name: "<input file stem>.sufr" in the current directory (sufr/src/lib.rs:334-340)
     std::string outfile;
     if (a->output) outfile = a->output;
@@ -285,29 +479,101 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
     if (a->is_dna) flags |= SUFR_HIP_FLAG_DNA;
     if (a->allow_ambiguity) flags |= SUFR_HIP_FLAG_ALLOW_AMBIGUITY;
     if (a->ignore_softmask) flags |= SUFR_HIP_FLAG_IGNORE_SOFTMASK;
+    const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
+    if (a->has_max_query_len && a->seed_mask) {                      // clap's conflicts_with; builder check 163-165
+        sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
+        sufr_sequence_data_free(&sd);
+        return SUFR_HIP_E_CONFLICT;
+    }
+    if (width == 4) {
+        // 32-bit indices: SA, LCP and the normalised text stay in HBM after the build and are streamed to the
+        // file by a few threads, each copying 32 MB pieces into its own pinned buffer and pwrite()-ing them
+        // at their final offset (every section's place in the file is known once s is).  On the test box
+        // the device-to-host side of this runs at ~37 GB/s and the page cache takes ~10 GB/s however many
+        // threads write (a shared mapping of the file instead of pwrite measured the same).
+        uint64_t s = 0;
+        int device = 0;
+        const void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr;
+        rc = sufr_hip_build_resident_(ctx, sd.seq, n, flags, mql, a->seed_mask, &s, stats, &device, &d_text, &d_sa,
+                                      &d_lcp);
+        if (rc != 0) { sufr_sequence_data_free(&sd); return rc; }
+        const double t_built = now_s();
+        const SufrLayout L = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, 4, s,
+                                         a->has_max_query_len, a->max_query_len, a->seed_mask, sd.start_positions,
+                                         sd.num_sequences, (const char* const*)sd.sequence_names);
+        int fd = ::open(outfile.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) {
+            sufr_hip_set_error_(ctx, (outfile + ": " + strerror(errno)).c_str());
+            sufr_sequence_data_free(&sd);
+            return SUFR_HIP_E_IO;
+        }
+        struct Piece { const uint8_t* src; uint64_t len, off; };
+        std::vector<Piece> pieces;
+        const uint64_t PIECE = (uint64_t)32 << 20;
+        auto add = [&](const void* base, uint64_t bytes, uint64_t file_off) {
+            for (uint64_t o = 0; o < bytes; o += PIECE)
+                pieces.push_back({(const uint8_t*)base + o, bytes - o < PIECE ? bytes - o : PIECE, file_off + o});
+        };
+        add(d_text, n, L.text_pos);
+        add(d_sa, s * 4, L.sa_pos);
+        add(d_lcp, s * 4, L.lcp_pos);
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        unsigned W = host_threads(12);
+        if (const char* e = getenv("SUFR_WRITE_THREADS")) if (atoi(e) > 0) W = (unsigned)atoi(e);
+        if (W > pieces.size()) W = (unsigned)(pieces.size() ? pieces.size() : 1);
+        auto worker = [&]() {
+            void* pin = nullptr;
+            hipStream_t st = nullptr;
+            if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, PIECE, hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                failed = 1;
+                if (pin) (void)hipHostFree(pin);
+                return;
+            }
+            for (size_t i; !failed && (i = next.fetch_add(1)) < pieces.size();) {
+                const Piece& pc = pieces[i];
+                if (hipMemcpyAsync(pin, pc.src, pc.len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { failed = 1; break; }
+                if (!pwrite_all(fd, pin, pc.len, pc.off)) { failed = 2; break; }
+            }
+            (void)hipStreamDestroy(st);
+            (void)hipHostFree(pin);
+        };
+        {
+            std::vector<std::thread> th;
+            for (unsigned w = 0; w < W; w++) th.emplace_back(worker);
+            if (!pwrite_all(fd, L.head.data(), L.head.size(), 0)) failed = 2;
+            if (!pwrite_all(fd, L.tail.data(), L.tail.size(), L.tail_pos)) failed = 2;
+            for (auto& x : th) x.join();
+        }
+        if (close(fd) != 0 && !failed) failed = 2;
+        if (failed) {
+            sufr_hip_set_error_(ctx, failed == 2 ? (outfile + ": write failed").c_str()
+                                                 : "device-to-host copy of the arrays failed");
+            rc = failed == 2 ? SUFR_HIP_E_IO : SUFR_HIP_E_HIP;
+        }
+        if (stats) {
+            stats->host_read_s = (float)(t_read - t_start);
+            stats->host_build_s = (float)(t_built - t_read);
+            stats->host_write_s = (float)(now_s() - t_built);
+        }
+        sufr_sequence_data_free(&sd);
+        return rc;
+    }
     std::vector<uint8_t> norm(n);
     uint64_t s = 0;
     void* sa = malloc((size_t)n * (size_t)width + 8);
     void* lcp = malloc((size_t)n * (size_t)width + 8);
     if (!sa || !lcp) { free(sa); free(lcp); sufr_sequence_data_free(&sd); return SUFR_HIP_E_NOMEM; }
-    const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
-    if (a->has_max_query_len && a->seed_mask) {
-        rc = SUFR_HIP_E_CONFLICT;    // clap's conflicts_with in the reference CLI; builder check 163-165
-    } else if (width == 4) {
-        rc = sufr_hip_build_u32(ctx, sd.seq, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
-                                norm.data(), (uint32_t*)sa, (uint32_t*)lcp, n, &s, stats);
-    } else {
-        rc = sufr_hip_build_u64(ctx, sd.seq, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
-                                norm.data(), (uint64_t*)sa, (uint64_t*)lcp, n, &s, stats);
-    }
+    rc = sufr_hip_build_u64(ctx, sd.seq, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
+                            norm.data(), (uint64_t*)sa, (uint64_t*)lcp, n, &s, stats);
     if (rc == 0) {
         rc = sufr_write_file(outfile.c_str(), a->is_dna, a->allow_ambiguity, a->ignore_softmask, norm.data(), n,
                              width, sa, lcp, s, a->has_max_query_len, a->max_query_len, a->seed_mask,
                              sd.start_positions, sd.num_sequences, (const char* const*)sd.sequence_names, err,
                              sizeof err);
         if (rc != 0) sufr_hip_set_error_(ctx, err);
-    } else if (rc == SUFR_HIP_E_CONFLICT) {
-        sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
     }
     free(sa); free(lcp);
     sufr_sequence_data_free(&sd);

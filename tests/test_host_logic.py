@@ -63,6 +63,37 @@ def test_read_sequence_file_variants(tmp_path):
     assert d.seq == b"ACGT%TTGA$" and d.sequence_names == ["r1", "r2"]
 
 
+def test_parallel_fasta_reader_equals_the_serial_one(tmp_path, monkeypatch):
+    """Files of 32 MB and more are read by several threads (line-aligned slices, two sweeps): same text,
+    start positions and names as the serial reader, with CRLF lines, blank lines, empty records, unnamed
+    records and a last line without a newline."""
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)
+    parts = []
+    for i in range(300):
+        ln = int(rng.integers(0, 260_000))
+        width = int(rng.choice([60, 70, 80, 1000]))
+        eol = b"\r\n" if i % 7 == 3 else b"\n"
+        hdr = b">" if i % 11 == 5 else b">seq%d some description" % i
+        parts.append(hdr + eol)
+        seq = acgt[rng.integers(0, acgt.size, size=ln)].tobytes()
+        for o in range(0, ln, width):
+            parts.append(seq[o:o + width] + eol)
+        if i % 13 == 0:
+            parts.append(eol)
+    blob = b"".join(parts)
+    blob = blob[:-1] if blob.endswith(b"\n") else blob
+    assert len(blob) > (32 << 20)
+    p = tmp_path / "big.fa"
+    p.write_bytes(blob)
+    par = sufr_amd.read_sequence_file(p)
+    monkeypatch.setenv("SUFR_SERIAL_READER", "1")
+    ser = sufr_amd.read_sequence_file(p)
+    assert par.seq == ser.seq
+    assert par.start_positions == ser.start_positions and par.sequence_names == ser.sequence_names
+    assert len(par.sequence_names) == 300 and par.seq.endswith(b"$")
+
+
 def test_empty_input_dies():  # cli.rs:103-110
     with pytest.raises(sufr_amd.SufrHipError):
         sufr_amd.read_sequence_file(GOLDEN / "inputs" / "empty.fa")
