@@ -157,6 +157,153 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_normalize_pack_dna: the same text map and run-end tables, specialised for the alphabet a DNA build
+// almost always has after normalisation: {'$', '%', 'A', 'C', 'G', 'N', 'T'}.  With the code table fixed in
+// advance (codes 1..7 in byte order, 3 bits) the bit-packed code stream can be written in this very pass
+// and the byte histogram shrinks to eight counters kept in registers; counts[8] counts bytes outside the set
+// -- if it is not zero the host falls back to k_normalize_bytehist and the general code table.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dna_fixed_code(uint32_t b)
+{
+    uint32_t c = 0;                  // 0: not in the set
+    c = b == 0x24u ? 1u : c;         // '$'
+    c = b == 0x25u ? 2u : c;         // '%'
+    c = b == 0x41u ? 3u : c;         // 'A'
+    c = b == 0x43u ? 4u : c;         // 'C'
+    c = b == 0x47u ? 5u : c;         // 'G'
+    c = b == 0x4eu ? 6u : c;         // 'N'
+    c = b == 0x54u ? 7u : c;         // 'T'
+    return c;
+}
+
+__global__ void __launch_bounds__(256)
+k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int normalize,
+                     int ignore_softmask, unsigned long long* __restrict__ counts,
+                     uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
+                     uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed)
+{
+    __shared__ uint16_t s_tab[256];          // normalised byte << 8 | fixed code (0 = not in the set)
+    __shared__ uint8_t s_first[256 + 4];
+    __shared__ uint32_t s_min;
+    __shared__ uint32_t s_any[2];
+    __shared__ __align__(16) uint16_t s_pack[256 * 3];
+    __shared__ unsigned long long s_tot[9];
+    {
+        uint32_t b = threadIdx.x;
+        if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
+        s_tab[threadIdx.x] = (uint16_t)((b << 8) | dna_fixed_code(b));
+    }
+    if (threadIdx.x < 9) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    // per-thread symbol counts: 4-bit lanes per half of the 16 bytes (<= 8 each), widened to 16-bit lanes
+    uint64_t acc_even = 0, acc_odd = 0;      // codes 0,2,4,6 / 1,3,5,7; code 0 = bytes outside the set
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * TILE + (uint64_t)threadIdx.x * 16;
+        uint32_t by[17];
+        if (threadIdx.x == 0) { s_min = 0xffffffffu; s_any[0] = 0; s_any[1] = 0; }
+        uint32_t vh = 0, vl = 0;             // codes of positions 0..7 / 8..15, 3 bits each, first highest
+        uint32_t na = 0, nb = 0;             // nibble counters of the two halves
+        if (p0 + 16 <= n) {
+            uint4 w = *reinterpret_cast<const uint4*>(in + p0);
+            uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t y = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t t = s_tab[(ws[k] >> (8 * j)) & 0xffu];
+                    const uint32_t b = t >> 8, c = t & 0xffu;
+                    by[4 * k + j] = b;
+                    y |= b << (8 * j);
+                    if (k < 2) { vh = (vh << 3) | c; na += 1u << (4 * c); }
+                    else { vl = (vl << 3) | c; nb += 1u << (4 * c); }
+                }
+                ws[k] = y;
+            }
+            *reinterpret_cast<uint4*>(out + p0) = make_uint4(ws[0], ws[1], ws[2], ws[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                by[e] = 0;
+                uint32_t c = 0;
+                if (p0 + e < n) {
+                    const uint32_t t = s_tab[in[p0 + e]];
+                    by[e] = t >> 8; c = t & 0xffu;
+                    out[p0 + e] = (uint8_t)by[e];
+                    if (e < 8) na += 1u << (4 * c); else nb += 1u << (4 * c);
+                }
+                if (e < 8) vh = (vh << 3) | c; else vl = (vl << 3) | c;
+            }
+        }
+        {
+            const uint32_t ea = na & 0x0f0f0f0fu, oa = (na >> 4) & 0x0f0f0f0fu;     // 8-bit lanes
+            const uint32_t eb = nb & 0x0f0f0f0fu, ob = (nb >> 4) & 0x0f0f0f0fu;
+            const uint32_t e8 = ea + eb, o8 = oa + ob;                               // <= 16 per lane
+            acc_even += (uint64_t)(e8 & 0xffu) | ((uint64_t)((e8 >> 8) & 0xffu) << 16) |
+                        ((uint64_t)((e8 >> 16) & 0xffu) << 32) | ((uint64_t)(e8 >> 24) << 48);
+            acc_odd += (uint64_t)(o8 & 0xffu) | ((uint64_t)((o8 >> 8) & 0xffu) << 16) |
+                       ((uint64_t)((o8 >> 16) & 0xffu) << 32) | ((uint64_t)(o8 >> 24) << 48);
+        }
+        const uint64_t V = ((uint64_t)vh << 24) | (uint64_t)vl;                      // 16 codes, 48 bits
+        s_first[threadIdx.x] = (uint8_t)by[0];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t hh = (uint32_t)(V >> (16 * (2 - k))) & 0xffffu;
+            s_pack[threadIdx.x * 3 + k] = (uint16_t)((hh >> 8) | (hh << 8));   // big-endian byte order
+        }
+        __syncthreads();
+        if (threadIdx.x < 255) by[16] = s_first[threadIdx.x + 1];
+        else by[16] = (p0 + 16 < n) ? (uint32_t)(s_tab[in[p0 + 16]] >> 8) : 0u;
+        {
+            uint4* dst = reinterpret_cast<uint4*>(packed + tile * (uint64_t)(TILE * 3 / 8));
+            const uint4* src = reinterpret_cast<const uint4*>(s_pack);
+            if (threadIdx.x < TILE * 3 / 8 / 16) dst[threadIdx.x] = src[threadIdx.x];
+        }
+        uint32_t best = 0xffffffffu;
+        uint32_t ends16 = 0;
+#pragma unroll
+        for (int e = 15; e >= 0; e--) {
+            uint64_t p = p0 + e;
+            if (p < n && (p == n - 1 || by[e] != by[e + 1])) { best = (uint32_t)p; ends16 |= 1u << e; }
+        }
+        if (best != 0xffffffffu) atomicMin(&s_min, best);
+        {
+            uint64_t v = (uint64_t)ends16 << (16 * (threadIdx.x & 3u));
+            v |= shfl64_xor(v, 1);
+            v |= shfl64_xor(v, 2);
+            if ((threadIdx.x & 3u) == 0) {
+                const uint32_t j = threadIdx.x >> 2;
+                run_ends[tile * 64 + j] = v;
+                if (v) atomicOr(&s_any[j >> 5], 1u << (j & 31u));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            first_end[tile] = s_min;
+            tile_any[tile] = (uint64_t)s_any[0] | ((uint64_t)s_any[1] << 32);
+        }
+        __syncthreads();
+    }
+    // eight symbol counts (code 0 = bytes outside the set): wave reduction, then one atomic per wave
+    uint32_t cnt[8];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cnt[2 * c] = (uint32_t)(acc_even >> (16 * c)) & 0xffffu;
+        cnt[2 * c + 1] = (uint32_t)(acc_odd >> (16 * c)) & 0xffffu;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        uint32_t v = cnt[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+        if (lane_id() == 0 && v) atomicAdd(&s_tot[c == 0 ? 8 : c], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 9 && s_tot[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_tot[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Key packing.  code(byte) in 1..sigma (dense rank of the byte among the bytes present in the text,
 // so integer order of codes == raw byte order); 0 = "past the end of the text" (sorts lowest,
 // sufr_builder.rs:372-379).  key = K codes of b bits, first character in the most significant bits.
@@ -415,6 +562,56 @@ k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS)
         if (s_flag[i]) flags[i] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_presence_hist_packed: k_digit_presence for a text whose packed code stream already exists, fused with
+// the pass-0 histogram of an unsharded build.  The dense digit remap is not known yet (it is derived from
+// the flags this kernel produces), so the histogram is taken on raw digit values, one row of raw_bins
+// counters per workgroup; k_densify_table folds the rows into the dense [workgroup][bin] table afterwards.
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__global__ void __launch_bounds__(THREADS)
+k_presence_hist_packed(uint64_t n, KeyParams kp, int shift, uint64_t chunk, uint32_t* __restrict__ flags,
+                       uint32_t* __restrict__ table_raw)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);                  // raw_bins (only with table_raw)
+    uint8_t* s_flag = smem + (table_raw ? (size_t)kp.raw_bins * 4 : 0);   // raw_bins
+    const uint32_t raw_mask = kp.raw_bins - 1;
+    for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS) { s_flag[i] = 0; if (table_raw) s_hist[i] = 0; }
+    __syncthreads();
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t c1 = min(c0 + chunk, n);
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
+        TileKeys tk;
+        build_keys_packed_t<B, EPT>(kp.packed, tile0 + (uint64_t)threadIdx.x * EPT, kp.elig_codes, tk.key, tk.elig);
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            s_flag[(uint32_t)(tk.key[e] >> kp.top_shift)] = 1;           // positions past n give digit 0
+            if (table_raw && (tk.elig & (1u << e)))
+                atomicAdd(&s_hist[(uint32_t)(tk.key[e] >> shift) & raw_mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS) {
+        if (s_flag[i]) flags[i] = 1u;
+        if (table_raw) table_raw[(size_t)blockIdx.x * kp.raw_bins + i] = s_hist[i];
+    }
+}
+
+// table[w][remap[v]] = table_raw[w][v] for every digit value v that occurs (table zeroed beforehand; the
+// remap is injective on the values that occur, all others have count 0)
+__global__ void __launch_bounds__(256)
+k_densify_table(const uint32_t* __restrict__ table_raw, const uint16_t* __restrict__ remap, uint32_t nwg,
+                uint32_t raw_bins, uint32_t nbins, uint32_t* __restrict__ table)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint64_t)nwg * raw_bins) return;
+    const uint32_t c = table_raw[i];
+    if (!c) return;
+    const uint32_t w = (uint32_t)(i / raw_bins), v = (uint32_t)(i % raw_bins);
+    table[(size_t)w * nbins + remap[v]] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
