@@ -180,8 +180,13 @@ __global__ void __launch_bounds__(256)
 k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int normalize,
                      int ignore_softmask, unsigned long long* __restrict__ counts,
                      uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
-                     uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed)
+                     uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed,
+                     uint32_t* __restrict__ top_rows, uint32_t elig_codes, uint32_t sample_stride)
 {
+    // top_rows (sharded builds only): per-workgroup counts of the first four characters of the suffixes
+    // that start in every sample_stride-th tile -- the "pivots chosen on device" of a multi-GPU job only need
+    // proportions (positions 13..15 of a thread's 16 are left out: their 4-mer crosses into the next thread)
+    __shared__ uint32_t s_top[4096];
     __shared__ uint16_t s_tab[256];          // normalised byte << 8 | fixed code (0 = not in the set)
     __shared__ uint8_t s_first[256 + 4];
     __shared__ uint32_t s_min;
@@ -194,6 +199,7 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
         s_tab[threadIdx.x] = (uint16_t)((b << 8) | dna_fixed_code(b));
     }
     if (threadIdx.x < 9) s_tot[threadIdx.x] = 0;
+    if (top_rows) for (int i = threadIdx.x; i < 4096; i += 256) s_top[i] = 0;
     __syncthreads();
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     // per-thread symbol counts: 4-bit lanes per half of the 16 bytes (<= 8 each), widened to 16-bit lanes
@@ -246,6 +252,13 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
                        ((uint64_t)((o8 >> 16) & 0xffu) << 32) | ((uint64_t)(o8 >> 24) << 48);
         }
         const uint64_t V = ((uint64_t)vh << 24) | (uint64_t)vl;                      // 16 codes, 48 bits
+        if (top_rows && tile % sample_stride == 0) {
+#pragma unroll
+            for (int e = 0; e <= 12; e++) {
+                const uint32_t mer = (uint32_t)(V >> (36 - 3 * e)) & 0xfffu;
+                if ((elig_codes >> (mer >> 9)) & 1u) atomicAdd(&s_top[mer], 1u);
+            }
+        }
         s_first[threadIdx.x] = (uint8_t)by[0];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -301,6 +314,7 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
     }
     __syncthreads();
     if (threadIdx.x < 9 && s_tot[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_tot[threadIdx.x]);
+    if (top_rows) for (int i = threadIdx.x; i < 4096; i += 256) top_rows[(size_t)blockIdx.x * 4096 + i] = s_top[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -566,14 +580,14 @@ k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
 
 // ---------------------------------------------------------------------------------------------
 // k_presence_hist_packed: k_digit_presence for a text whose packed code stream already exists, fused with
-// the pass-0 histogram of an unsharded build.  The dense digit remap is not known yet (it is derived from
+// the pass-0 histogram (of the suffixes whose raw top digit lies in [top_lo, top_hi): the shard filter).  The dense digit remap is not known yet (it is derived from
 // the flags this kernel produces), so the histogram is taken on raw digit values, one row of raw_bins
 // counters per workgroup; k_densify_table folds the rows into the dense [workgroup][bin] table afterwards.
 // ---------------------------------------------------------------------------------------------
 template <int B>
 __global__ void __launch_bounds__(THREADS)
-k_presence_hist_packed(uint64_t n, KeyParams kp, int shift, uint64_t chunk, uint32_t* __restrict__ flags,
-                       uint32_t* __restrict__ table_raw)
+k_presence_hist_packed(uint64_t n, KeyParams kp, int shift, uint64_t chunk, uint32_t top_lo, uint32_t top_hi,
+                       uint32_t* __restrict__ flags, uint32_t* __restrict__ table_raw)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);                  // raw_bins (only with table_raw)
@@ -588,8 +602,9 @@ k_presence_hist_packed(uint64_t n, KeyParams kp, int shift, uint64_t chunk, uint
         build_keys_packed_t<B, EPT>(kp.packed, tile0 + (uint64_t)threadIdx.x * EPT, kp.elig_codes, tk.key, tk.elig);
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
-            s_flag[(uint32_t)(tk.key[e] >> kp.top_shift)] = 1;           // positions past n give digit 0
-            if (table_raw && (tk.elig & (1u << e)))
+            const uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift);
+            s_flag[top] = 1;                                              // positions past n give digit 0
+            if (table_raw && (tk.elig & (1u << e)) && top >= top_lo && top < top_hi)   // raw range of the shard
                 atomicAdd(&s_hist[(uint32_t)(tk.key[e] >> shift) & raw_mask], 1u);
         }
     }
