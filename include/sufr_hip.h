@@ -68,7 +68,7 @@ typedef struct sufr_hip_stats {
     uint64_t deep_records;      /* records processed by deeper levels (all levels) */
     uint32_t top_lo, top_hi;    /* prefix-bucket range of this shard [lo, hi) */
     uint32_t partition_workgroups; /* grid of the radix-partition kernel */
-    uint32_t partition_variant; /* 0 = k_scatter_text (4096-position tiles), 1 = k_scatter_text_sparse (8192) */
+    uint32_t partition_variant; /* 0 = k_scatter_text (4096-position tiles), 1 = k_scatter_text_sparse (8192), 2 = k_scatter_text_accum */
     float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
     float ms_normalize;         /* k_normalize_bytehist */
     float ms_hist_text;         /* k_hist_text (+ table scan) */

@@ -971,6 +971,7 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
 // two half-tile flushes where a tile holds more than CAP suffix starts.
 // ---------------------------------------------------------------------------------------------
 static constexpr int SPARSE_NT = 512, SPARSE_E = 16, SPARSE_CAP = 4864;
+static constexpr int ACCUM_CAP = 4096;     // k_scatter_text_accum: 8 staged records per thread fit the register budget
 
 template <int B, bool SHARDED>
 __global__ void __launch_bounds__(SPARSE_NT)
@@ -1060,6 +1061,151 @@ k_scatter_text_sparse(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter_text_accum: the partition pass of a rank that keeps only a small part of the suffixes (one of
+// N >= 4 prefix-bucket shards: 1/N of ~half of the positions).  An 8192-position tile then holds a few
+// hundred kept records, and zeroing / scanning ~640 digit counters plus the barriers around them for every
+// tile costs more than the records themselves.  Kept (key, index) pairs are therefore appended to the LDS
+// staging area tile after tile; only when the next (half) tile might not fit are they ranked by digit,
+// re-placed in digit order (every thread holds its records in registers meanwhile) and written out.
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__global__ void __launch_bounds__(SPARSE_NT)
+k_scatter_text_accum(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
+                     uint32_t top_lo, uint32_t top_hi, const uint32_t* __restrict__ table,
+                     const uint32_t* __restrict__ binbase, uint64_t* __restrict__ out_key,
+                     uint32_t* __restrict__ out_idx)
+{
+    constexpr int NT = SPARSE_NT, E = SPARSE_E, CAP = ACCUM_CAP;
+    constexpr int TILEB = NT * E;
+    constexpr int PER = (CAP + NT - 1) / NT;               // staged records per thread at a flush (registers)
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t NB = kp.nbins;
+    const uint32_t NBa = (NB + 3u) & ~3u;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_gbase = s_cnt + NBa;
+    uint32_t* s_gdelta = s_gbase + NBa;
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);      // CAP
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + CAP);         // CAP
+    uint32_t* s_misc = s_idx + CAP;                                      // 32
+    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 32);           // raw_bins
+
+    const uint32_t raw_mask = kp.raw_bins - 1;
+    const uint32_t* row = table + (size_t)blockIdx.x * NB;
+    for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
+    const uint16_t* s_remap = nullptr;
+    if (gremap) {
+        for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += NT) s_rm[i] = gremap[i];
+        s_remap = s_rm;
+    }
+    uint32_t pending = 0;                                  // staged records (the same value in every thread)
+
+    auto flush = [&]() {
+        __syncthreads();                                   // appended records are visible
+        for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
+        uint64_t rk[PER];
+        uint32_t ri[PER], rd[PER], rr[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t j = threadIdx.x + (uint32_t)k * NT;
+            rk[k] = 0; ri[k] = 0;
+            if (j < pending) { rk[k] = s_key[j]; ri[k] = s_idx[j]; }
+            rd[k] = digit_of(rk[k], shift, raw_mask, s_remap);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            rr[k] = (threadIdx.x + (uint32_t)k * NT < pending) ? atomicAdd(&s_cnt[rd[k]], 1u) : 0u;
+        __syncthreads();
+        block_scan_bins_t<NT>(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (threadIdx.x + (uint32_t)k * NT < pending) {
+                const uint32_t pos = s_cnt[rd[k]] + rr[k];
+                s_key[pos] = rk[k];
+                s_idx[pos] = ri[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < pending; j += NT) {
+            const uint64_t k = s_key[j];
+            const uint32_t o = j + s_gdelta[digit_of(k, shift, raw_mask, s_remap)];
+            out_key[o] = k;
+            out_idx[o] = s_idx[j];
+        }
+        __syncthreads();                                   // the staging area is free again
+        pending = 0;
+    };
+
+    // keys and shard filter of one tile; called again after a flush so that no key is live across it
+    auto tile_keys16 = [&](uint64_t tile0, uint64_t (&key)[E], uint32_t& keep) {
+        build_keys_packed_t<B, E>(kp.packed, tile0 + (uint64_t)threadIdx.x * E, kp.elig_codes, key, keep);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t top = (uint32_t)(key[e] >> kp.top_shift) & raw_mask;
+            if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
+        }
+    };
+    auto append = [&](uint64_t tile0, const uint64_t (&key)[E], uint32_t bits, int first, uint32_t at) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if (e >= first && (bits & (1u << e))) {
+                s_key[at] = key[e];
+                s_idx[at] = (uint32_t)(tile0 + (uint64_t)threadIdx.x * E + (uint32_t)e);
+                at++;
+            }
+        }
+    };
+
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
+    const uint64_t c1 = min(c0 + chunk, n);
+    __syncthreads();
+    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
+        uint64_t key[E];
+        uint32_t keep;
+        tile_keys16(tile0, key, keep);
+        // kept records of the two half tiles, packed as lo | hi << 16, scanned over the workgroup
+        const uint32_t mine = (uint32_t)__popc(keep & 0x00ffu) | ((uint32_t)__popc(keep & 0xff00u) << 16);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, WAVE);
+            if ((int)lane_id() >= o) incl += t;
+        }
+        if (lane_id() == 63) s_misc[8 + (threadIdx.x >> 6)] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+            const uint32_t t = s_misc[8 + w];
+            if (w < (int)(threadIdx.x >> 6)) before += t;
+            total += t;
+        }
+        const uint32_t excl = before + incl - mine;
+        const uint32_t t_lo = total & 0xffffu, t_hi = total >> 16;          // each <= 4096 <= CAP
+        const uint32_t x_lo = excl & 0xffffu, x_hi = excl >> 16;
+        if (pending + t_lo + t_hi > (uint32_t)CAP) {
+            flush();
+            tile_keys16(tile0, key, keep);
+        }
+        if (t_lo + t_hi <= (uint32_t)CAP) {
+            // both halves: the low half's records first, then the high half's
+            append(tile0, key, keep & 0x00ffu, 0, pending + x_lo);
+            append(tile0, key, keep & 0xff00u, 8, pending + t_lo + x_hi);
+            pending += t_lo + t_hi;
+        } else {                                           // a dense tile: one half at a time
+            append(tile0, key, keep & 0x00ffu, 0, pending + x_lo);
+            pending += t_lo;
+            flush();
+            tile_keys16(tile0, key, keep);
+            append(tile0, key, keep & 0xff00u, 8, pending + x_hi);
+            pending += t_hi;
+        }
+        __syncthreads();                                   // s_misc is reused by the next tile
+    }
+    if (pending) flush();
 }
 
 // ---------------------------------------------------------------------------------------------
