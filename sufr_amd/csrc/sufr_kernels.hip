@@ -314,7 +314,11 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
     }
     __syncthreads();
     if (threadIdx.x < 9 && s_tot[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_tot[threadIdx.x]);
-    if (top_rows) for (int i = threadIdx.x; i < 4096; i += 256) top_rows[(size_t)blockIdx.x * 4096 + i] = s_top[i];
+    // with gridDim a multiple of the stride only every sample_stride-th workgroup ever meets a sampled tile
+    // (tile = blockIdx + k * gridDim): those workgroups own the rows
+    if (top_rows && blockIdx.x % sample_stride == 0)
+        for (int i = threadIdx.x; i < 4096; i += 256)
+            top_rows[(size_t)(blockIdx.x / sample_stride) * 4096 + i] = s_top[i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -332,6 +332,8 @@ def test_device_api_and_shards_concatenate(oracle):
         for r in range(shards):
             psa, plcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, shard_index=r,
                                 num_shards=shards)
+            # 1/2 of ~47 % kept -> 8192-position tiles; 1/8 -> records accumulated over several tiles
+            assert db.stats.partition_variant == (1 if shards == 2 else 2)
             psa = psa.cpu().numpy().view(np.uint32).copy(); plcp = plcp.cpu().numpy().view(np.uint32).copy()
             if parts_sa and psa.size:      # boundary stitch: find_lcp(prev.last, this.first) (893-902)
                 prev = next(p for p in reversed(parts_sa) if p.size)
