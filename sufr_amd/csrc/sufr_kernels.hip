@@ -1234,8 +1234,28 @@ k_hist_pairs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ seg
         for (uint32_t j = c0 + threadIdx.x; j < c1; j += THREADS)
             atomicAdd(&s_cnt[(seg[j] >> shift) & mask], 1u);
     } else {
-        for (uint32_t j = c0 + threadIdx.x; j < c1; j += THREADS)
-            atomicAdd(&s_cnt[digit_of(keys[j], shift, mask, s_remap)], 1u);
+        // four 16-byte loads (two keys each) in flight per lane: 16 waves per CU then keep ~64 KB of reads
+        // outstanding, which a streaming read needs to approach the HBM rate
+        const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys + c0);   // c0 is a multiple of 8192
+        const uint32_t npair = (c1 - c0) >> 1;
+        uint32_t i = threadIdx.x;
+        for (; i + 3u * THREADS < npair; i += 4u * THREADS) {
+            ulonglong2 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q[u] = k2[i + (uint32_t)u * THREADS];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                atomicAdd(&s_cnt[digit_of(q[u].x, shift, mask, s_remap)], 1u);
+                atomicAdd(&s_cnt[digit_of(q[u].y, shift, mask, s_remap)], 1u);
+            }
+        }
+        for (; i < npair; i += THREADS) {
+            const ulonglong2 q = k2[i];
+            atomicAdd(&s_cnt[digit_of(q.x, shift, mask, s_remap)], 1u);
+            atomicAdd(&s_cnt[digit_of(q.y, shift, mask, s_remap)], 1u);
+        }
+        if (((c1 - c0) & 1u) && threadIdx.x == 0)
+            atomicAdd(&s_cnt[digit_of(keys[c1 - 1], shift, mask, s_remap)], 1u);
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * nbins;
