@@ -1305,7 +1305,7 @@ __device__ __forceinline__ void match_digit_t(uint32_t d, int nbits, bool valid,
     }
 }
 
-template <bool HAS_SEG, int NT, int E, int NBITS>
+template <bool HAS_SEG, int NT, int E, int NBITS, bool DIAG>
 __global__ void __launch_bounds__(NT)
 k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict__ in_idx,
                 const uint32_t* __restrict__ in_seg, uint32_t m, uint32_t nbins, int nbits,
@@ -1315,11 +1315,13 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx,
                 uint32_t* __restrict__ out_seg, int ablate, unsigned long long* __restrict__ stamps)
 {
-    // diagnostic build path (ablate & 16): thread 0 accumulates s_memtime deltas per phase into stamps[]
+    // DIAG instances only (SUFR_HIP_PAIRS_ABLATE): ablation switches, and with bit 16 thread 0 accumulates
+    // s_memtime deltas per phase into stamps[]; the production instances carry none of this
+    if (!DIAG) ablate = 0;
     unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamping = (ablate & 16) && threadIdx.x == 0;
+    const bool stamping = DIAG && (ablate & 16) && threadIdx.x == 0;
 #define SUFR_STAMP(i)                                                        \
-    if (stamping) {                                                          \
+    if (DIAG && stamping) {                                                  \
         unsigned long long t_now = __builtin_amdgcn_s_memtime();             \
         t_acc[i] += t_now - t_prev;                                          \
         t_prev = t_now;                                                      \
