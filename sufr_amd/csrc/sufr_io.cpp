@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
+#include <zlib.h>
 
 #include "../../include/sufr_hip.h"
 
@@ -319,12 +320,40 @@ int sufr_read_sequence_file(const char* path, uint8_t delimiter, sufr_sequence_d
     if (!fv.open(path, why)) { put_err(err, errlen, why); return SUFR_HIP_E_IO; }
     const uint8_t* p = fv.data;
     const uint8_t* end = fv.data + fv.size;
-    while (p < end && (*p == '\n' || *p == '\r' || *p == ' ' || *p == '\t')) p++;
-    if (p >= end) { put_err(err, errlen, std::string(path) + ": empty sequence file"); return SUFR_HIP_E_IO; }
+    // gzip input (needletail, which the reference reads with, decompresses transparently): inflated into
+    // memory first (concatenated members included), then parsed like a plain file
+    std::vector<uint8_t> inflated;
     if (fv.size >= 2 && fv.data[0] == 0x1f && fv.data[1] == 0x8b) {
-        put_err(err, errlen, std::string(path) + ": compressed input is not supported");
+        gzFile gz = gzopen(path, "rb");
+        if (!gz) { put_err(err, errlen, std::string(path) + ": cannot open gzip stream"); return SUFR_HIP_E_IO; }
+        gzbuffer(gz, 1u << 20);
+        inflated.resize(fv.size * 4 + (1u << 20));
+        size_t have = 0;
+        for (;;) {
+            if (inflated.size() - have < (1u << 20)) inflated.resize(inflated.size() * 2);
+            const size_t room = inflated.size() - have;
+            int got = gzread(gz, inflated.data() + have, (unsigned)(room > (1u << 30) ? (1u << 30) : room));
+            if (got < 0) {
+                int zerr = 0;
+                const char* msg = gzerror(gz, &zerr);
+                put_err(err, errlen, std::string(path) + ": " + (msg ? msg : "gzip error"));
+                gzclose(gz);
+                return SUFR_HIP_E_IO;
+            }
+            if (got == 0) break;
+            have += (size_t)got;
+        }
+        gzclose(gz);
+        inflated.resize(have);
+        p = inflated.data();
+        end = inflated.data() + inflated.size();
+    } else if (fv.size >= 3 && ((fv.data[0] == 'B' && fv.data[1] == 'Z' && fv.data[2] == 'h') ||
+                                (fv.data[0] == 0xfd && fv.data[1] == '7' && fv.data[2] == 'z'))) {
+        put_err(err, errlen, std::string(path) + ": bzip2 / xz input is not supported (gzip and plain text are)");
         return SUFR_HIP_E_UNSUPPORTED;
     }
+    while (p < end && (*p == '\n' || *p == '\r' || *p == ' ' || *p == '\t')) p++;
+    if (p >= end) { put_err(err, errlen, std::string(path) + ": empty sequence file"); return SUFR_HIP_E_IO; }
     if (*p != '>' && *p != '@') {
         put_err(err, errlen, std::string(path) + ": expected a FASTA ('>') or FASTQ ('@') record");
         return SUFR_HIP_E_IO;
@@ -356,7 +385,7 @@ int sufr_read_sequence_file(const char* path, uint8_t delimiter, sufr_sequence_d
         return 0;
     }
     std::vector<uint8_t> seq;
-    seq.reserve(fv.size + 1);
+    seq.reserve((size_t)(end - p) + 1);
     std::vector<uint64_t> starts;
     std::vector<std::string> names;
     while (p < end) {

@@ -75,6 +75,15 @@ def test_native_cli_binary_golden(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Wrote 260 bytes" in r.stdout
     assert out.read_bytes() == (GOLDEN / "expected" / "2.sufr").read_bytes()
+    # gzip input (needletail inflates it transparently in the reference)
+    import gzip
+    gz = tmp_path / "two.fa.gz"
+    gz.write_bytes(gzip.compress((GOLDEN / "inputs" / "2.fa").read_bytes()))
+    out_gz = tmp_path / "2gz.sufr"
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "create", "--dna", "-n", "2", "-o", str(out_gz), str(gz)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out_gz.read_bytes() == (GOLDEN / "expected" / "2.sufr").read_bytes()
     # default output name: <input stem>.sufr in the CWD (sufr/src/lib.rs:334-340)
     r = subprocess.run([str(sufr_amd.CLI_PATH), "cr", "-d", str(GOLDEN / "inputs" / "1.fa")], cwd=tmp_path,
                        capture_output=True, text=True)

@@ -94,6 +94,29 @@ def test_parallel_fasta_reader_equals_the_serial_one(tmp_path, monkeypatch):
     assert len(par.sequence_names) == 300 and par.seq.endswith(b"$")
 
 
+def test_gzip_input_reads_like_plain_text(tmp_path):
+    """needletail (the reference's reader) inflates gzip transparently; so does this reader, including
+    concatenated members.  bzip2 / xz are refused loudly."""
+    import gzip
+    plain = (GOLDEN / "inputs" / "long_dna_sequence.fa").read_bytes()
+    want = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "long_dna_sequence.fa")
+    one = tmp_path / "a.fa.gz"
+    one.write_bytes(gzip.compress(plain))
+    half = len(plain) // 2
+    two = tmp_path / "b.fa.gz"
+    two.write_bytes(gzip.compress(plain[:half]) + gzip.compress(plain[half:]))
+    for p in (one, two):
+        got = sufr_amd.read_sequence_file(p)
+        assert (got.seq, got.start_positions, got.sequence_names) == (want.seq, want.start_positions,
+                                                                        want.sequence_names)
+    import bz2
+    bad = tmp_path / "c.fa.bz2"
+    bad.write_bytes(bz2.compress(plain))
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        sufr_amd.read_sequence_file(bad)
+    assert "not supported" in str(e.value)
+
+
 def test_empty_input_dies():  # cli.rs:103-110
     with pytest.raises(sufr_amd.SufrHipError):
         sufr_amd.read_sequence_file(GOLDEN / "inputs" / "empty.fa")
