@@ -70,9 +70,9 @@ typedef struct sufr_hip_stats {
     uint32_t partition_workgroups; /* grid of the radix-partition kernel */
     uint32_t partition_variant; /* 0 = k_scatter_text (4096-position tiles), 1 = k_scatter_text_sparse (8192), 2 = k_scatter_text_accum */
     float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
-    float ms_normalize;         /* k_normalize_bytehist */
-    float ms_hist_text;         /* k_hist_text (+ table scan) */
-    float ms_partition;         /* k_scatter_text: THE radix-partition kernel (one launch) */
+    float ms_normalize;         /* k_normalize_pack_dna / k_normalize_bytehist */
+    float ms_hist_text;         /* pass-0 histogram: k_hist_text, or k_densify_table when it was taken in the presence pass (+ table scan) */
+    float ms_partition;         /* k_scatter_text[_sparse|_accum]: THE radix-partition kernel (one launch) */
     float ms_passes;            /* remaining LSD passes */
     float ms_finish;            /* k_finish of the top level */
     float ms_deep;              /* all deeper levels */

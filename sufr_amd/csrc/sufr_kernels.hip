@@ -1,10 +1,12 @@
 // sufr_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for suffix-array + LCP construction.
 //
 // Replaces the CPU hot loops of the reference builder (libsufr/src/sufr_builder.rs):
-//   * text normalisation            (143-160)  -> k_normalize_bytehist
+//   * text normalisation            (143-160)  -> k_normalize_pack_dna / k_normalize_bytehist (+ run-end
+//                                                 tables, bit-packed code stream)
 //   * eligibility + upper_bound/is_less/find_lcp bucketing (346-394, 442-462)
-//                                              -> k_hist_text / k_scatter_text (radix partition on
-//                                                 packed k-char prefix keys, LDS staged)
+//                                              -> k_presence_hist_packed | k_digit_presence + k_hist_text,
+//                                                 then k_scatter_text / _sparse / _accum (radix partition
+//                                                 on packed k-char prefix keys, LDS staged)
 //   * merge_sort / merge            (601-767)  -> k_hist_pairs / k_scatter_pairs (further LSD passes)
 //                                                 + k_finish (wave-level tie refinement, exact LCP)
 //   * boundary LCP of write()       (886-906)  -> LCP at every group boundary comes from the key xor
@@ -413,7 +415,6 @@ __device__ __forceinline__ void build_tile_keys_fast(const uint8_t* s_code, Tile
     for (int e = 0; e < EPT; e++) {
         tk.key[e] = key;
         if ((w[e >> 2] >> (8 * (e & 3))) & 0x80u) tk.elig |= 1u << e;
-        constexpr int dummy = 0; (void)dummy;
         uint64_t c = (w[(e + K) >> 2] >> (8 * ((e + K) & 3))) & 0x7fu;
         key = (key << B) | (c << low);
     }
@@ -436,7 +437,6 @@ __device__ __forceinline__ void build_keys_packed_t(const uint8_t* __restrict__ 
     elig = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        constexpr int dummy = 0; (void)dummy;
         const int s = e * B;
         const uint64_t v = s ? ((hi << s) | (lo >> (64 - s))) : hi;
         key[e] = v & keep;
