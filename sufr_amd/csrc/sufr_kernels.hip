@@ -324,6 +324,64 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// next_tile[t] = smallest t' >= t whose tile holds a run end (RunTable).  Backward "nearest set flag" over
+// the tiles in three small steps: inside blocks of 256 tiles (ballots), over the block heads (one
+// workgroup, in LDS), then the tiles that found nothing inside their block take their block's successor.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t nearest_at_or_after(bool has, uint32_t my_index, uint32_t* s_first /*[4]*/)
+{
+    // 256 threads; returns the index of the nearest thread >= this one (in thread order) with `has`, else RUN_NONE
+    const uint64_t m = __ballot(has);
+    const uint32_t ln = lane_id();
+    const uint64_t at = m >> ln;
+    uint32_t r = at ? my_index + (uint32_t)__builtin_ctzll(at) : RUN_NONE;
+    if (ln == 0) s_first[threadIdx.x >> 6] = r;          // first in this wave (lane 0 sees the whole mask)
+    __syncthreads();
+    for (int w = (threadIdx.x >> 6) + 1; w < 4 && r == RUN_NONE; w++) r = s_first[w];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_next_tile_blocks(const uint32_t* __restrict__ first_end, uint32_t ntiles, uint32_t* __restrict__ next_tile,
+                   uint32_t* __restrict__ block_first)
+{
+    __shared__ uint32_t s_first[4];
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const bool has = t < ntiles && first_end[t] != RUN_NONE;
+    const uint32_t r = nearest_at_or_after(has, t, s_first);
+    if (t < ntiles) next_tile[t] = r;
+    if (threadIdx.x == 0) block_first[blockIdx.x] = r;
+}
+
+__global__ void __launch_bounds__(256)
+k_next_tile_heads(uint32_t* __restrict__ block_first, uint32_t nblocks)
+{
+    // in place: block_first[b] := first tile with a run end in the blocks AFTER b.  At most 4096 blocks
+    // (2^32 text bytes / 4096 / 256): staged in LDS, one thread walks them from the end.
+    __shared__ uint32_t s_b[4096];
+    for (uint32_t i = threadIdx.x; i < nblocks; i += 256) s_b[i] = block_first[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t nxt = RUN_NONE;
+        for (int64_t b = (int64_t)nblocks - 1; b >= 0; b--) {
+            const uint32_t own = s_b[b];
+            s_b[b] = nxt;
+            if (own != RUN_NONE) nxt = own;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nblocks; i += 256) block_first[i] = s_b[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_next_tile_apply(uint32_t* __restrict__ next_tile, uint32_t ntiles, const uint32_t* __restrict__ block_after)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < ntiles && next_tile[t] == RUN_NONE) next_tile[t] = block_after[blockIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Key packing.  code(byte) in 1..sigma (dense rank of the byte among the bytes present in the text,
 // so integer order of codes == raw byte order); 0 = "past the end of the text" (sorts lowest,
 // sufr_builder.rs:372-379).  key = K codes of b bits, first character in the most significant bits.

@@ -12,7 +12,8 @@
 
 namespace sufr {
 
-static constexpr uint32_t RUN_SAT = 65535u;   // saturation of run lengths inside run keys
+static constexpr uint32_t RUN_SAT = (1u << 30) - 1u;   // saturation of plain run lengths inside run keys (gamma code <= 61 bits)
+static constexpr uint32_t PERIOD_SAT = 65535u;         // saturation of periodic extensions (found by a word-wise scan)
 static constexpr uint32_t RUN_TILE = 4096u;   // granularity of the run-end table (== TILE of the kernels)
 static constexpr uint32_t RUN_NONE = 0xffffffffu;
 
@@ -21,10 +22,13 @@ static constexpr uint32_t RUN_NONE = 0xffffffffu;
 //   ends[w]      bit i set: position 64 w + i is a run end                  (n / 8 bytes)
 //   tile_any[t]  bit j set: ends[64 t + j] != 0                             (8 bytes per 4096-byte tile)
 //   first_end[t] first run end of tile t, RUN_NONE if there is none         (4 bytes per tile)
+//   next_tile[t] smallest t' >= t whose tile holds a run end                (4 bytes per tile)
+// so the length of a run is found in a handful of loads whether it is 3 bytes or 30 million.
 struct RunTable {
     const uint64_t* ends;
     const uint64_t* tile_any;
     const uint32_t* first_end;
+    const uint32_t* next_tile;
     uint32_t ntiles;
 };
 
@@ -65,14 +69,14 @@ SUFR_HD uint32_t plain_key_common(uint64_t a, uint64_t b, int bits, int K)
 // All suffixes of a group agree on their first `q - idx` characters, in particular on c = text[q-1].
 // The key describes the text from q on as
 //     cls | gamma(rem + 1) [complemented if cls] | the characters after the run, b bits each
-//   rem = number of further bytes equal to c starting at q (0 if text[q] != c), saturating at 65535;
+//   rem = number of further bytes equal to c starting at q (0 if text[q] != c), saturating at RUN_SAT;
 //   x   = the byte after that run (end of text sorts lowest);   cls = (x > c).
 // Comparing  c^remA xA...  with  c^remB xB...:  if the runs differ in length, the shorter one is
 // smaller iff its x is below c -- so  {x < c, rem ascending} < {x > c, rem descending}; the Elias-gamma
 // code (L ones, a zero, L low bits) is order preserving and its complement reverses the order.
 // A saturated run has x == c, cls = 0 and continues with real text characters, which keeps the order.
 // The integer order of run keys therefore equals the suffix order, and a run of any length costs one
-// R lookup instead of a byte-by-byte walk.
+// run-table lookup instead of a byte-by-byte walk.
 // ---------------------------------------------------------------------------------------------
 struct RunTok { uint32_t cls, rem; int tokbits; };
 
@@ -83,7 +87,7 @@ SUFR_HD RunTok decode_run_token(uint64_t key)
     uint64_t g = key << 1;
     if (t.cls) g = ~g;
     int L = g == ~0ull ? 63 : __builtin_clzll(~g);    // leading ones
-    if (L > 16) L = 16;                        // rem + 1 <= 65536
+    if (L > 30) L = 30;                        // rem + 1 <= 2^30
     uint32_t low = L ? (uint32_t)((g << (L + 1)) >> (64 - L)) : 0u;
     t.rem = ((1u << L) | low) - 1u;
     t.tokbits = 2 + 2 * L;
@@ -109,12 +113,12 @@ SUFR_HD uint32_t run_key_advance(uint64_t key, int sorted_bits, int bits)
 }
 
 // periodic extension length for period pi > 1: number of bytes from q on that equal the byte pi
-// positions earlier, capped at RUN_SAT (word-wise scan; tandem arrays are kilobases, not megabases)
+// positions earlier, capped at PERIOD_SAT (word-wise scan; tandem arrays are kilobases, not megabases)
 SUFR_HD uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint64_t q,
                                                  uint32_t pi)
 {
     uint32_t rem = 0;
-    while (rem < RUN_SAT && q + rem < n) {
+    while (rem < PERIOD_SAT && q + rem < n) {
         uint64_t a = load_u64_unaligned(text + q + rem);
         uint64_t b = load_u64_unaligned(text + q + rem - pi);
         uint64_t x = a ^ b;
@@ -124,13 +128,13 @@ SUFR_HD uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint
         rem += same;
         if (same < 8) break;
     }
-    return rem < RUN_SAT ? rem : RUN_SAT;
+    return rem < PERIOD_SAT ? rem : PERIOD_SAT;
 }
 
 // min(RUN_SAT, length of the run of equal bytes that starts at q), q < n; runs end at the end of the text.
 // Genomes built with --ignore-softmask are ~50 % 'N' in runs of hundreds to millions of bytes, and the
 // reference walks through them byte by byte inside find_lcp (sufr_builder.rs:301-331).  Here a run of any
-// length costs one bitmap word, at most two more loads inside its 4 KB tile, then the tiles after it.
+// length costs one bitmap word, at most two more loads inside its 4 KB tile, and two for all tiles after it.
 SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
 {
     uint64_t w = q >> 6;
@@ -143,14 +147,10 @@ SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
             w = (tile << 6) + (uint64_t)__builtin_ctzll(later);
             m = rt.ends[w];
         } else {
-            for (uint64_t t = tile + 1; t < rt.ntiles && t <= tile + 17; t++) {      // 17 tiles > RUN_SAT bytes
-                const uint32_t fe = rt.first_end[t];
-                if (fe != RUN_NONE) {
-                    const uint64_t len = (uint64_t)fe - q + 1;
-                    return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
-                }
-            }
-            return RUN_SAT;
+            if (tile + 1 >= rt.ntiles) return RUN_SAT;                     // cannot happen: n-1 is a run end
+            const uint32_t fe = rt.first_end[rt.next_tile[tile + 1]];
+            const uint64_t len = (uint64_t)fe - q + 1;
+            return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
         }
     }
     const uint64_t len = (w << 6) + (uint64_t)__builtin_ctzll(m) - q + 1;

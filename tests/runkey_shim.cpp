@@ -6,15 +6,15 @@
 
 extern "C" {
 
-// reference for run_len_at: min(65535, run of equal bytes starting at p, ending at n), one byte at a time
-void shim_run_lengths(const uint8_t* text, uint64_t n, uint16_t* R)
+// reference for run_len_at: min(RUN_SAT, run of equal bytes starting at p, ending at n), one byte at a time
+void shim_run_lengths(const uint8_t* text, uint64_t n, uint32_t* R)
 {
     uint64_t p = n;
     uint32_t run = 0;
     while (p-- > 0) {
         if (p + 1 < n && text[p + 1] == text[p]) run = run < sufr::RUN_SAT ? run + 1 : sufr::RUN_SAT;
         else run = 1;
-        R[p] = (uint16_t)run;
+        R[p] = run;
     }
 }
 // the run-end tables k_normalize_bytehist writes (RunTable of sufr_runkey.h); ends: 64 words per tile
@@ -36,13 +36,22 @@ void shim_run_table(const uint8_t* text, uint64_t n, uint64_t* ends, uint64_t* t
 static sufr::RunTable shim_table(uint64_t n, const uint64_t* ends)
 {
     // layout used by the tests: [ends: 64 words per tile][tile_any: 1 word per tile][first_end: u32 per tile]
+    //                           [next_tile: u32 per tile]
     const uint64_t ntiles = (n + sufr::RUN_TILE - 1) / sufr::RUN_TILE;
-    return sufr::RunTable{ends, ends + ntiles * 64, (const uint32_t*)(ends + ntiles * 65), (uint32_t)ntiles};
+    const uint32_t* fe = (const uint32_t*)(ends + ntiles * 65);
+    return sufr::RunTable{ends, ends + ntiles * 64, fe, fe + ntiles, (uint32_t)ntiles};
 }
 void shim_run_table_packed(const uint8_t* text, uint64_t n, uint64_t* buf)
 {
     const uint64_t ntiles = (n + sufr::RUN_TILE - 1) / sufr::RUN_TILE;
-    shim_run_table(text, n, buf, buf + ntiles * 64, (uint32_t*)(buf + ntiles * 65));
+    uint32_t* fe = (uint32_t*)(buf + ntiles * 65);
+    shim_run_table(text, n, buf, buf + ntiles * 64, fe);
+    uint32_t* nt = fe + ntiles;                           // what the k_next_tile_* kernels compute
+    uint32_t nxt = sufr::RUN_NONE;
+    for (uint64_t t = ntiles; t-- > 0;) {
+        if (fe[t] != sufr::RUN_NONE) nxt = (uint32_t)t;
+        nt[t] = nxt;
+    }
 }
 uint32_t shim_run_len_at(uint64_t n, uint64_t q, const uint64_t* tab)
 {

@@ -123,7 +123,7 @@ def test_run_len_at_matches_bytewise_runs(shim):
     the text (zero bytes included: the padding after the text is zero too)."""
     rng = np.random.default_rng(3)
     parts = []
-    for ln in [1, 2, 7, 8, 9, 63, 4095, 4096, 4097, 3, 12_000, 5, 70_000, 1, 140_000, 2, 66_000]:
+    for ln in [1, 2, 7, 8, 9, 63, 4095, 4096, 4097, 3, 12_000, 5, 70_000, 1, 140_000, 2, 66_000, 4, 3_000_000]:
         parts.append(np.full(ln, rng.integers(0, 4), dtype=np.uint8))
         parts.append(rng.integers(4, 9, size=int(rng.integers(1, 40)), dtype=np.uint8))
     for tail in [np.empty(0, np.uint8), np.zeros(9000, np.uint8), np.full(5000, 65, np.uint8)]:
@@ -131,7 +131,7 @@ def test_run_len_at_matches_bytewise_runs(shim):
         # adjacent equal values across part boundaries merge into longer runs: that is fine
         n = t.size
         buf = np.zeros(n + PAD, dtype=np.uint8); buf[:n] = t
-        want = np.zeros(n + PAD, dtype=np.uint16)
+        want = np.zeros(n + PAD, dtype=np.uint32)
         shim.shim_run_lengths(buf.ctypes.data, n, want.ctypes.data)
         tab = np.zeros((n // 4096 + 2) * 66, dtype=np.uint64)
         shim.shim_run_table_packed(buf.ctypes.data, n, tab.ctypes.data)
