@@ -1879,14 +1879,27 @@ __global__ void __launch_bounds__(256)
 k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, RunTable R,
               const uint16_t* __restrict__ glut, const uint32_t* __restrict__ idx,
               const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth,
-              const uint8_t* __restrict__ segperiod, uint32_t m, KeyParams kp, uint64_t* __restrict__ keys)
+              const uint8_t* __restrict__ segperiod, uint32_t m, KeyParams kp, uint64_t* __restrict__ keys,
+              uint32_t* __restrict__ max_token_bits)
 {
     __shared__ uint16_t s_lut[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= m) return;
-    keys[e] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]], kp.packed);
+    uint32_t tb = 0;
+    if (e < m) {
+        const uint64_t k =
+            make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]], kp.packed);
+        keys[e] = k;
+        tb = (uint32_t)decode_run_token(k).tokbits;
+    }
+    // longest run token of the level: the level must sort at least that many key bits, otherwise a group
+    // whose members differ only inside their tokens would be re-keyed at the same depth for ever
+    if (max_token_bits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tb = max(tb, (uint32_t)__shfl_down(tb, o, WAVE));
+        if (lane_id() == 0 && tb > 34u) atomicMax(max_token_bits, tb);
+    }
 }
 
 // size of every large group (upper bound of (segment, sorted bits) in the sorted records) and the depth

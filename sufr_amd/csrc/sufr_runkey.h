@@ -12,7 +12,8 @@
 
 namespace sufr {
 
-static constexpr uint32_t RUN_SAT = (1u << 30) - 1u;   // saturation of plain run lengths inside run keys (gamma code <= 61 bits)
+static constexpr uint32_t RUN_SAT = (1u << 29) - 1u;   // saturation of plain run lengths inside run keys: token <= 60 bits,
+                                                       // which five 12-bit passes of a re-keying level can still sort
 static constexpr uint32_t PERIOD_SAT = 65535u;         // saturation of periodic extensions (found by a word-wise scan)
 static constexpr uint32_t RUN_TILE = 4096u;   // granularity of the run-end table (== TILE of the kernels)
 static constexpr uint32_t RUN_NONE = 0xffffffffu;
@@ -87,7 +88,7 @@ SUFR_HD RunTok decode_run_token(uint64_t key)
     uint64_t g = key << 1;
     if (t.cls) g = ~g;
     int L = g == ~0ull ? 63 : __builtin_clzll(~g);    // leading ones
-    if (L > 30) L = 30;                        // rem + 1 <= 2^30
+    if (L > 29) L = 29;                        // rem + 1 <= 2^29
     uint32_t low = L ? (uint32_t)((g << (L + 1)) >> (64 - L)) : 0u;
     t.rem = ((1u << L) | low) - 1u;
     t.tokbits = 2 + 2 * L;

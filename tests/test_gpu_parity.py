@@ -263,6 +263,43 @@ def test_only_ineligible(ctx, oracle):
     assert b.num_suffixes == 0
 
 
+def _rle_lcp_and_order(t: np.ndarray, starts: np.ndarray, a: int, b: int):
+    """exact LCP of suffixes a, b and whether a < b, walking runs instead of bytes (t has few long runs)"""
+    n = t.size
+    k = 0
+    while True:
+        pa, pb = a + k, b + k
+        if pa >= n or pb >= n:
+            return k, pa >= n and pb < n
+        if t[pa] != t[pb]:
+            return k, t[pa] < t[pb]
+        ea = starts[np.searchsorted(starts, pa, side="right")]      # end (exclusive) of pa's run
+        eb = starts[np.searchsorted(starts, pb, side="right")]
+        k += int(min(ea - pa, eb - pb))
+
+
+def test_allow_ambiguity_runs_beyond_2_pow_16_bytes(ctx):
+    """Runs of 2^16 bytes and more make run tokens longer than the 34 bits a re-keying level sorts by default;
+    the level then sorts as many digits as its longest token needs.  Checked against an exact run-walking
+    comparison on sampled adjacent ranks."""
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = [acgt[rng.integers(0, 4, 40)], np.full(300_000, ord("N"), np.uint8), acgt[rng.integers(0, 4, 25)],
+             np.full(299_990, ord("N"), np.uint8), acgt[rng.integers(0, 4, 33)], np.full(70_000, ord("N"), np.uint8),
+             acgt[rng.integers(0, 4, 12)], np.full(300_000, ord("N"), np.uint8), np.frombuffer(b"$", dtype=np.uint8)]
+    raw = np.concatenate(parts)
+    b = gpu_build(ctx, raw, allow_ambiguity=True)
+    assert b.num_suffixes == raw.size
+    sa = b.suffix_array.astype(np.int64); lcp = b.lcp.astype(np.int64)
+    assert np.array_equal(np.sort(sa), np.arange(raw.size))
+    change = np.flatnonzero(raw[1:] != raw[:-1]) + 1
+    starts = np.concatenate([[0], change, [raw.size]])            # run starts, then n as the final end
+    for r in rng.integers(1, sa.size, 40_000).tolist():
+        k, less = _rle_lcp_and_order(raw, starts, int(sa[r - 1]), int(sa[r]))
+        assert less and lcp[r] == k, (r, int(sa[r - 1]), int(sa[r]), k, int(lcp[r]))
+    assert int(lcp.max()) >= 299_990
+
+
 @pytest.mark.parametrize("kind", ["all_a", "acgt_k", "fib", "two_identical", "n_run", "tandem"])
 @pytest.mark.parametrize("n", [100, 5000])
 def test_adversarial_micro_inputs(ctx, oracle, kind, n):
