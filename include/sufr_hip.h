@@ -122,8 +122,8 @@ int sufr_hip_sort_device_u32(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, 
                              void *d_sa, void *d_lcp, uint64_t cap,
                              uint64_t *num_suffixes_out, sufr_hip_stats *stats);
 /* u64-index twin (SufrBuilder<u64>; suffix_array.rs:461 selects it when n >= u32::MAX).  Texts below
- * 2^32-1 bytes are built with 32-bit indices on the device and widened; longer texts return
- * SUFR_HIP_E_UNSUPPORTED for now. */
+ * 2^32 - 2^24 bytes are built with 32-bit indices on the device and widened; longer texts return
+ * SUFR_HIP_E_UNSUPPORTED for now (the u32 entry points have the same limit). */
 int sufr_hip_sort_device_u64(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,
                              uint64_t max_query_len, const char *seed_mask,
                              uint64_t num_partitions, uint64_t random_seed,
