@@ -90,6 +90,17 @@ def test_native_cli_binary_golden(tmp_path):
     assert r.returncode == 0 and (tmp_path / "1.sufr").read_bytes() == (GOLDEN / "expected" / "1.sufr").read_bytes()
 
 
+def test_create_reports_an_unwritable_output(tmp_path):
+    """"{filename}: {io error}" like SufrBuilder::write (sufr_builder.rs:820), exit code 1 from the binary"""
+    bad = tmp_path / "no_such_dir" / "x.sufr"
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        sufr_amd.create(str(GOLDEN / "inputs" / "1.fa"), str(bad), is_dna=True)
+    assert str(bad) in str(e.value) and "No such file or directory" in str(e.value)
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "create", "-d", "-o", str(bad), str(GOLDEN / "inputs" / "1.fa")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Error: ") and str(bad) in r.stderr
+
+
 def test_lib_rs_inline_vectors(ctx):  # libsufr/src/lib.rs:45-140
     d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "2.fa", b"N")
     b = gpu_build(ctx, np.frombuffer(d.seq, dtype=np.uint8))
