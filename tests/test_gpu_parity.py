@@ -579,3 +579,62 @@ def test_elegans_config_c3_properties(oracle):
         off += k
     assert off == full_sa.numel()
     db.close()
+
+
+def test_human_config_c4_properties():
+    """BASELINE config C4 size (3.1 Gb stand-in, --dna --ignore-softmask): size-independent properties checked
+    on the GPU itself -- SA is a permutation of the eligible positions (count, sum and a weighted checksum
+    against the eligibility mask), 3e5 sampled adjacent ranks are in order with the exact LCP (window of 512
+    characters; longer LCPs are checked for >= 511 agreement), and 8 shards concatenate to the same arrays."""
+    x, _ = synth.syn_human(3_100_000_000, seed=4, device="cuda")
+    n = x.numel()
+    db = sufr_amd.DeviceBuilder(0)
+    out_sa = torch.empty(1_530_000_000, dtype=torch.int32, device="cuda")
+    out_lcp = torch.empty_like(out_sa)
+    sa, lcp = db.sort(x, is_dna=True, ignore_softmask=True, raw_text=True, out_sa=out_sa, out_lcp=out_lcp)
+    s = sa.numel()
+    lut = torch.arange(256, dtype=torch.uint8, device="cuda")
+    lut[97:123] = 78                                          # lowercase -> 'N' (sufr_builder.rs:144-160)
+    elig = torch.zeros(256, dtype=torch.bool, device="cuda")
+    for c in b"ACGT$":
+        elig[c] = True
+    # permutation of the eligible positions
+    cnt = 0; tot = 0; wtot = 0
+    for lo in range(0, n, 1 << 28):
+        blk = lut[x[lo:lo + (1 << 28)].long()]
+        m = elig[blk.long()]
+        pos = torch.arange(lo, lo + blk.numel(), device="cuda")[m]
+        cnt += int(m.sum()); tot += int(pos.sum()); wtot += int((pos * (pos % 1009)).sum())
+    assert cnt == s
+    p64 = sa.to(torch.int64) & 0xFFFFFFFF
+    M64 = (1 << 64) - 1                                       # the weighted sums wrap: compare modulo 2^64
+    assert int(p64.sum()) == tot and (int((p64 * (p64 % 1009)).sum()) & M64) == (wtot & M64)
+    assert int(lcp[0]) == 0
+    # order and exact LCP on sampled adjacent ranks
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    W = 512
+    ar = torch.arange(W, device="cuda")
+    for _ in range(3):
+        pick = torch.randint(1, s, (100_000,), generator=g, device="cuda")
+        a = p64[pick - 1]; b = p64[pick]
+        want = lcp[pick].to(torch.int64) & 0xFFFFFFFF
+        ia = a[:, None] + ar[None, :]; ib = b[:, None] + ar[None, :]
+        ta = torch.where(ia < n, lut[x[ia.clamp(max=n - 1)].long()].to(torch.int16), torch.tensor(-1, dtype=torch.int16, device="cuda"))
+        tb = torch.where(ib < n, lut[x[ib.clamp(max=n - 1)].long()].to(torch.int16), torch.tensor(-1, dtype=torch.int16, device="cuda"))
+        diff = ta != tb
+        anyd = diff.any(1)
+        first = torch.where(anyd, diff.float().argmax(1), torch.full_like(pick, W))
+        short = want < W
+        assert bool(torch.all(first[short] == want[short])) and bool(torch.all(first[~short] == W))
+        fa = ta.gather(1, first.clamp(max=W - 1)[:, None])[:, 0]; fb = tb.gather(1, first.clamp(max=W - 1)[:, None])[:, 0]
+        assert bool(torch.all(fa[short] < fb[short]))
+    # 8 prefix-bucket shards: identical arrays apart from the stitched first LCP of shards 1..7
+    full_sa, full_lcp = sa.clone(), lcp.clone()
+    off = 0
+    for r in range(8):
+        psa, plcp = db.sort(x, is_dna=True, ignore_softmask=True, raw_text=True, shard_index=r, num_shards=8)
+        k = psa.numel()
+        assert k > 0 and torch.equal(psa, full_sa[off:off + k]) and torch.equal(plcp[1:], full_lcp[off + 1:off + k])
+        off += k
+    assert off == s
+    db.close()
