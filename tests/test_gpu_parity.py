@@ -16,6 +16,10 @@ from oracle_helper import GOLDEN, GOLDEN_CASES, check_sa_lcp_properties, naive_s
 
 pytestmark = pytest.mark.gpu
 
+# tuning knobs (SUFR_HIP_*) switch kernel variants: results must not change, variant assertions are skipped
+import os
+_KNOBS_SET = any(k.startswith("SUFR_HIP_") for k in os.environ)
+
 
 @pytest.fixture(scope="module")
 def ctx():
@@ -220,7 +224,8 @@ def test_sparse_partition_kernel_both_flush_modes(ctx, oracle):
     raw = np.concatenate(parts + [np.frombuffer(b"$", dtype=np.uint8)])
     b = assert_matches_oracle(ctx, oracle, raw)
     assert b.num_suffixes <= 0.55 * raw.size
-    assert b.stats.partition_variant == 1
+    if not _KNOBS_SET:
+        assert b.stats.partition_variant == 1
 
 
 def test_empty_text(ctx):
@@ -390,7 +395,8 @@ def test_device_api_and_shards_concatenate(oracle):
             psa, plcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, shard_index=r,
                                 num_shards=shards)
             # 1/2 of ~47 % kept -> 8192-position tiles; 1/8 -> records accumulated over several tiles
-            assert db.stats.partition_variant == (1 if shards == 2 else 2)
+            if not _KNOBS_SET:
+                assert db.stats.partition_variant == (1 if shards == 2 else 2)
             psa = psa.cpu().numpy().view(np.uint32).copy(); plcp = plcp.cpu().numpy().view(np.uint32).copy()
             if parts_sa and psa.size:      # boundary stitch: find_lcp(prev.last, this.first) (893-902)
                 prev = next(p for p in reversed(parts_sa) if p.size)
