@@ -104,6 +104,49 @@ def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: f
                       f"sort {st.t_sort:.2f} s)"}
 
 
+def e2e_create(text_cpu: np.ndarray, starts, flags: dict, partitions: int, s_total: int):
+    """`sufr create` end to end (t_create): the synthetic text written as a FASTA file, then
+    the native CLI from FASTA parse to the closed .sufr file.  Reported next to `value`, never as `value`."""
+    import shutil
+    import subprocess
+    import tempfile
+    need = int(text_cpu.size * 1.03) + 8 * s_total + text_cpu.size + (64 << 20)
+    tmp = Path(tempfile.mkdtemp(prefix="sufr_e2e_", dir=os.environ.get("TMPDIR", "/tmp")))
+    try:
+        if shutil.disk_usage(tmp).free < need * 1.2:
+            return {"skipped": f"needs {need >> 20} MiB of scratch space in {tmp.parent}"}
+        fa, out = tmp / "in.fa", tmp / "out.sufr"
+        body = text_cpu[:-1]
+        cuts = list(starts) + [body.size + 1]
+        with open(fa, "wb") as f:
+            for i in range(len(starts)):
+                seq = body[cuts[i]:cuts[i + 1] - 1]
+                f.write(f">seq{i + 1} synthetic\n".encode())
+                full = (seq.size // 60) * 60
+                if full:
+                    f.write(np.concatenate([seq[:full].reshape(-1, 60),
+                                            np.full((full // 60, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+                if seq.size > full:
+                    f.write(seq[full:].tobytes() + b"\n")
+        cmd = [str(sufr_amd.CLI_PATH), "--log", "debug", "create", "-n", str(partitions), "-o", str(out), str(fa)]
+        for flag, opt in (("is_dna", "--dna"), ("ignore_softmask", "--ignore-softmask"), ("allow_ambiguity", "-a")):
+            if flags.get(flag):
+                cmd.insert(cmd.index("-n"), opt)
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr.strip()[-200:]}
+        phases = [ln for ln in r.stdout.splitlines() if "host phases" in ln]
+        return {"seconds": dt, "suffixes_per_s": s_total / dt, "fasta_bytes": fa.stat().st_size,
+                "sufr_bytes": out.stat().st_size, "phases": phases[-1].split("host phases: ")[-1] if phases else None,
+                "what": "native `sufr create`: FASTA parse, H2D, build, D2H, .sufr written (process start-up included)"}
+    except Exception as e:      # the headline number must not depend on scratch space or a subprocess
+        return {"error": repr(e)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +155,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SUFR_BENCH_WORKLOAD", "human"), choices=sorted(WORKLOADS))
     ap.add_argument("--bases", type=int, default=int(os.environ.get("SUFR_BENCH_BASES", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `sufr create` measurement (N=1 only)")
     ap.add_argument("--placement-trials", type=int, default=int(os.environ.get("SUFR_BENCH_PLACEMENT_TRIALS", "3")),
                     help="contexts (work-buffer placements) tried before timing; the fastest is kept (1 = off)")
     ap.add_argument("--verify", action="store_true", help="check SA/LCP properties on sampled ranks after timing")
@@ -267,6 +311,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sample_bases = min(bases, 400_000_000)
             out["cpu_baseline"] = cpu_baseline(text[:sample_bases].cpu().numpy(), flags, partitions)
+        if world == 1 and not args.no_e2e:
+            builder.close()          # the CLI is its own process with its own context: free this one's HBM first
+            out["e2e_create"] = e2e_create(text.cpu().numpy(), starts, flags, partitions, s_total)
         print(json.dumps(out), flush=True)
     builder.close()
     if world > 1:
