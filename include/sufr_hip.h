@@ -191,6 +191,12 @@ typedef struct sufr_create_args {
 } sufr_create_args;
 int sufr_hip_create_file(sufr_hip_ctx *ctx, const sufr_create_args *args, char *path_out,
                          size_t path_out_len, sufr_hip_stats *stats);
+/* The same from sequence data the caller has already read (sufr_read_sequence_file): lets a driver read
+ * the file while the device context is being created.  `seq` is not modified and stays the caller's;
+ * args->input only names the default output ("<input stem>.sufr"). */
+int sufr_hip_create_from_sequence(sufr_hip_ctx *ctx, const sufr_sequence_data *seq,
+                                  const sufr_create_args *args, char *path_out, size_t path_out_len,
+                                  sufr_hip_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -58,7 +58,7 @@ EXPORTS = [
     "sufr_hip_abi_version", "sufr_hip_device_count", "sufr_hip_create", "sufr_hip_destroy",
     "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
     "sufr_hip_sort_device_u64", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
-    "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file",
+    "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file", "sufr_hip_create_from_sequence",
 ]
 
 _lib = None

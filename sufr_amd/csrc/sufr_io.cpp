@@ -478,16 +478,13 @@ int sufr_write_file(const char* path, int is_dna, int allow_ambiguity, int ignor
     return 0;
 }
 
-int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* path_out, size_t path_out_len,
-                         sufr_hip_stats* stats)
+int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* sdp, const sufr_create_args* a,
+                                  char* path_out, size_t path_out_len, sufr_hip_stats* stats)
 {
-    if (!ctx || !a || !a->input) return SUFR_HIP_E_INVALID;
+    if (!ctx || !a || !a->input || !sdp || !sdp->seq) return SUFR_HIP_E_INVALID;
     char err[512] = {0};
-    sufr_sequence_data sd;
-    const double t_start = now_s();
-    int rc = sufr_read_sequence_file(a->input, a->sequence_delimiter ? a->sequence_delimiter : (uint8_t)'%', &sd,
-                                     err, sizeof err);
-    if (rc != 0) { sufr_hip_set_error_(ctx, err); return rc; }
+    const sufr_sequence_data& sd = *sdp;
+    int rc = 0;
     const double t_read = now_s();
     // default output name: "<input file stem>.sufr" in the current directory (sufr/src/lib.rs:334-340)
     std::string outfile;
@@ -511,7 +508,6 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
     const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
     if (a->has_max_query_len && a->seed_mask) {                      // clap's conflicts_with; builder check 163-165
         sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
-        sufr_sequence_data_free(&sd);
         return SUFR_HIP_E_CONFLICT;
     }
     if (width == 4) {
@@ -525,7 +521,7 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
         const void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr;
         rc = sufr_hip_build_resident_(ctx, sd.seq, n, flags, mql, a->seed_mask, &s, stats, &device, &d_text, &d_sa,
                                       &d_lcp);
-        if (rc != 0) { sufr_sequence_data_free(&sd); return rc; }
+        if (rc != 0) return rc;
         const double t_built = now_s();
         const SufrLayout L = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, 4, s,
                                          a->has_max_query_len, a->max_query_len, a->seed_mask, sd.start_positions,
@@ -533,8 +529,7 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
         int fd = ::open(outfile.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) {
             sufr_hip_set_error_(ctx, (outfile + ": " + strerror(errno)).c_str());
-            sufr_sequence_data_free(&sd);
-            return SUFR_HIP_E_IO;
+                return SUFR_HIP_E_IO;
         }
         struct Piece { const uint8_t* src; uint64_t len, off; };
         std::vector<Piece> pieces;
@@ -583,18 +578,17 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
             rc = failed == 2 ? SUFR_HIP_E_IO : SUFR_HIP_E_HIP;
         }
         if (stats) {
-            stats->host_read_s = (float)(t_read - t_start);
+            stats->host_read_s = 0.0f;                         // filled in by sufr_hip_create_file
             stats->host_build_s = (float)(t_built - t_read);
             stats->host_write_s = (float)(now_s() - t_built);
         }
-        sufr_sequence_data_free(&sd);
         return rc;
     }
     std::vector<uint8_t> norm(n);
     uint64_t s = 0;
     void* sa = malloc((size_t)n * (size_t)width + 8);
     void* lcp = malloc((size_t)n * (size_t)width + 8);
-    if (!sa || !lcp) { free(sa); free(lcp); sufr_sequence_data_free(&sd); return SUFR_HIP_E_NOMEM; }
+    if (!sa || !lcp) { free(sa); free(lcp); return SUFR_HIP_E_NOMEM; }
     rc = sufr_hip_build_u64(ctx, sd.seq, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
                             norm.data(), (uint64_t*)sa, (uint64_t*)lcp, n, &s, stats);
     if (rc == 0) {
@@ -605,6 +599,23 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
         if (rc != 0) sufr_hip_set_error_(ctx, err);
     }
     free(sa); free(lcp);
+    return rc;
+}
+
+
+int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* path_out, size_t path_out_len,
+                         sufr_hip_stats* stats)
+{
+    if (!ctx || !a || !a->input) return SUFR_HIP_E_INVALID;
+    char err[512] = {0};
+    sufr_sequence_data sd;
+    const double t_start = now_s();
+    int rc = sufr_read_sequence_file(a->input, a->sequence_delimiter ? a->sequence_delimiter : (uint8_t)'%', &sd,
+                                     err, sizeof err);
+    if (rc != 0) { sufr_hip_set_error_(ctx, err); return rc; }
+    const double t_read = now_s();
+    rc = sufr_hip_create_from_sequence(ctx, &sd, a, path_out, path_out_len, stats);
+    if (stats) stats->host_read_s = (float)(t_read - t_start);
     sufr_sequence_data_free(&sd);
     return rc;
 }
