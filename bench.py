@@ -133,7 +133,7 @@ def e2e_create(text_cpu: np.ndarray, starts, flags: dict, partitions: int, s_tot
             if flags.get(flag):
                 cmd.insert(cmd.index("-n"), opt)
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": r.stderr.strip()[-200:]}
