@@ -557,6 +557,55 @@ def test_fuzz_shards_concatenate_to_the_single_build(block):
     db.close()
 
 
+@pytest.mark.parametrize("kind", range(8))
+def test_fuzz_structured_texts_against_oracle(ctx, oracle, kind):
+    """20 k - 400 k texts with the structures that stress different parts of the pipeline: families of
+    near-identical copies, tandem arrays of several periods, N runs with lowercase, long homopolymers, protein,
+    exact duplicates of long segments, a two-letter alphabet."""
+    rng = np.random.default_rng(700 + kind)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for case in range(5):
+        n = int(rng.integers(20_000, 400_000))
+        t = acgt[rng.integers(0, 4, n)]
+        if kind == 1:
+            fam = acgt[rng.integers(0, 4, int(rng.integers(200, 3000)))]
+            for _ in range(int(rng.integers(5, 200))):
+                at = int(rng.integers(0, n - fam.size)); c = fam.copy()
+                hit = rng.random(fam.size) < rng.choice([0.0, 0.001, 0.02, 0.1])
+                c[hit] = acgt[rng.integers(0, 4, int(hit.sum()))]
+                t[at:at + fam.size] = c
+        elif kind == 2:
+            for _ in range(30):
+                u = acgt[rng.integers(0, 4, int(rng.integers(1, 12)))]
+                ln = int(rng.integers(50, 5000)); at = int(rng.integers(0, n - ln))
+                t[at:at + ln] = np.resize(u, ln)
+        elif kind == 3:
+            t = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[rng.integers(0, 9, n)]
+            for _ in range(40):
+                ln = int(rng.integers(1, 900)); at = int(rng.integers(0, n - ln)); t[at:at + ln] = ord("N")
+        elif kind == 4:
+            for _ in range(10):
+                ln = int(rng.integers(100, 30000)); at = int(rng.integers(0, n - ln))
+                t[at:at + ln] = acgt[rng.integers(0, 4)]
+        elif kind == 5:
+            t = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)[rng.integers(0, 20, n)]
+        elif kind == 6:
+            for _ in range(6):
+                ln = int(rng.integers(500, 20000)); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+                t[b:b + ln] = t[a:a + ln].copy()
+        elif kind == 7:
+            t = acgt[rng.integers(0, 2, n)]
+        t = t.copy()
+        for c in rng.integers(1, n - 1, size=int(rng.integers(0, 5))):
+            t[c] = ord("%")
+        raw = np.concatenate([t, np.frombuffer(b"$", dtype=np.uint8)])
+        soft = bool(rng.random() < 0.5)
+        amb = bool(kind == 3 and rng.random() < 0.5)
+        if amb:
+            raw = _break_long_n_runs(raw, soft)
+        assert_matches_oracle(ctx, oracle, raw, is_dna=kind != 5, allow_ambiguity=amb, ignore_softmask=soft)
+
+
 # ---- BASELINE-sized property checks ---------------------------------------------------------------------
 def test_elegans_config_c3_properties(oracle):
     """BASELINE config C3 size (100 Mb, 7 sequences): too big for the oracle in seconds, so check the
