@@ -62,18 +62,18 @@ typedef struct sufr_hip_stats {
     uint32_t bits_per_char;     /* b */
     uint32_t chars_per_key;     /* K */
     uint32_t digit_bits;        /* radix digit width */
-    uint32_t num_passes;        /* LSD passes of the top level */
+    uint32_t num_passes;        /* MSD levels of the top level (1 = the text partition only) */
     uint32_t num_levels;        /* 1 + re-keying levels needed for long repeats */
     uint64_t num_large_groups;  /* groups handed to deeper levels (all levels) */
     uint64_t deep_records;      /* records processed by deeper levels (all levels) */
     uint32_t top_lo, top_hi;    /* prefix-bucket range of this shard [lo, hi) */
     uint32_t partition_workgroups; /* grid of the radix-partition kernel */
-    uint32_t partition_variant; /* 0 = k_scatter_text (4096-position tiles), 1 = k_scatter_text_sparse (8192), 2 = k_scatter_text_accum */
+    uint32_t partition_variant; /* 3 = k_msd_scatter_text (bit-packed stream, alphabets of <= 15 symbols), 0 = k_scatter_text (text staging) */
     float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
     float ms_normalize;         /* k_normalize_pack_dna / k_normalize_bytehist */
-    float ms_hist_text;         /* pass-0 histogram: k_hist_text, or k_densify_table when it was taken in the presence pass (+ table scan) */
-    float ms_partition;         /* k_scatter_text[_sparse|_accum]: THE radix-partition kernel (one launch) */
-    float ms_passes;            /* remaining LSD passes */
+    float ms_hist_text;         /* level-1 histogram over the text (k_msd_hist_text / k_hist_text) + cursor setup */
+    float ms_partition;         /* k_msd_scatter_text / k_scatter_text: THE radix-partition kernel (one launch) */
+    float ms_passes;            /* further MSD levels + leaf sorts */
     float ms_finish;            /* k_finish of the top level */
     float ms_deep;              /* all deeper levels */
     /* host phases of sufr_hip_create_file (seconds; 0 from the other entry points) */

@@ -21,8 +21,6 @@ struct KeyParams {
     int top_shift;  // 64 - dbits: the most significant digit (shard selector)
     const uint8_t* packed; // text as a big-endian stream of b-bit codes (b <= 4), or nullptr
     uint32_t elig_codes;   // bit c set: a suffix may start with the character whose code is c (b <= 4)
-    int skip_inelig;       // scatter_text: threads whose positions are all ineligible skip the key build
-    int ablate;            // timing experiments only (SUFR_HIP_ABLATE); 0 in production
     int detect_period; // deep levels: use periodic run tokens for groups whose common prefix is periodic
 };
 

@@ -961,16 +961,9 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
             uint32_t any = 0;
 #pragma unroll
             for (int v = 0; v < E / 8; v++) { uint2 q = own[v]; any |= (q.x | q.y) & 0x80808080u; }
-            if (any || !kp.skip_inelig) build_keys_t<B, E>(s_tile, key, elig);
+            if (any) build_keys_t<B, E>(s_tile, key, elig);
         } else {
             build_keys_generic_t<E>(s_tile, s_lut, tile0, n, kp.b, kp.K, key, elig);
-        }
-        if (kp.ablate & 4) {       // timing experiment: stop after the key build
-            uint64_t acc = 0;
-#pragma unroll
-            for (int e = 0; e < E; e++) if (elig & (1u << e)) acc ^= key[e];
-            if (acc == 0x123456789ull) out_key[0] = acc;
-            continue;
         }
         // digit lookups for all E positions first (independent LDS reads in flight together), then the
         // ranking atomics under the eligibility mask: no load -> atomic dependency inside a branch
@@ -1007,267 +1000,14 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
             }
         }
         __syncthreads();
-        if (kp.ablate & 2) continue;      // timing experiment: no copy-out at all
         for (uint32_t j = threadIdx.x; j < total; j += NT) {
             const uint32_t pe = s_idx[j];
             const uint32_t slot = pe >> 12, d = pe & 0xfffu;
             const uint32_t o = j + s_gdelta[d];
-            if (kp.ablate & 1) {          // timing experiment: LDS side of the copy-out, no global stores
-                if (s_key[slot] == 0x123456789ull && o == 77) out_idx[0] = 1;
-                continue;
-            }
             out_key[o] = s_key[slot];
             out_idx[o] = (uint32_t)(tile0 + slot);
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_scatter_text_sparse: the same partition pass for texts in which at most about half of the positions
-// are suffix starts (a soft-masked genome built with --ignore-softmask is ~50 % 'N'; a shard of an N-GPU job
-// keeps 1/N of the suffixes).  The length of the run a tile contributes to a digit decides how well the
-// scattered stores fill HBM sectors, and a 4096-position tile of such a text yields only ~3 records per
-// digit.  This variant takes 8192 positions per tile (16 per thread, still one 16-byte window load), keeps
-// only the kept records in LDS -- placed directly at their ranked slot, 12 bytes each, so the staging area
-// is sized by CAP records instead of by positions and two workgroups still fit a CU -- and falls back to
-// two half-tile flushes where a tile holds more than CAP suffix starts.
-// ---------------------------------------------------------------------------------------------
-static constexpr int SPARSE_NT = 512, SPARSE_E = 16, SPARSE_CAP = 4864;
-static constexpr int ACCUM_CAP = 4096;     // k_scatter_text_accum: 8 staged records per thread fit the register budget
-
-template <int B, bool SHARDED>
-__global__ void __launch_bounds__(SPARSE_NT)
-k_scatter_text_sparse(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
-                      uint32_t top_lo, uint32_t top_hi, const uint32_t* __restrict__ table,
-                      const uint32_t* __restrict__ binbase, uint64_t* __restrict__ out_key,
-                      uint32_t* __restrict__ out_idx)
-{
-    constexpr int NT = SPARSE_NT, E = SPARSE_E, CAP = SPARSE_CAP;
-    constexpr int TILEB = NT * E;                          // 8192 positions: 13 bits in the staged entry
-    extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t NB = kp.nbins;
-    const uint32_t NBa = (NB + 3u) & ~3u;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_gbase = s_cnt + NBa;
-    uint32_t* s_gdelta = s_gbase + NBa;
-    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);      // CAP, in digit order
-    uint32_t* s_pv = reinterpret_cast<uint32_t*>(s_key + CAP);          // CAP: digit << 13 | position in tile
-    uint32_t* s_misc = s_pv + CAP;                                       // 32
-    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 32);           // raw_bins
-
-    const uint32_t raw_mask = kp.raw_bins - 1;
-    const uint32_t* row = table + (size_t)blockIdx.x * NB;
-    for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
-    const uint16_t* s_remap = nullptr;
-    if (gremap) {
-        for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += NT) s_rm[i] = gremap[i];
-        s_remap = s_rm;
-    }
-    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
-    const uint64_t c1 = min(c0 + chunk, n);
-    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
-        __syncthreads();                                   // the previous copy-out is done with the staging area
-        for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
-        uint64_t key[E];
-        uint32_t keep;
-        build_keys_packed_t<B, E>(kp.packed, tile0 + (uint64_t)threadIdx.x * E, kp.elig_codes, key, keep);
-        uint32_t dig[E], rank[E];
-        if constexpr (SHARDED) {
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const uint32_t top = (uint32_t)(key[e] >> kp.top_shift) & raw_mask;
-                if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
-            }
-        }
-        // digit lookups only for kept positions (all issued before the first is used)
-#pragma unroll
-        for (int e = 0; e < E; e++) dig[e] = (keep & (1u << e)) ? digit_of(key[e], shift, raw_mask, s_remap) : 0u;
-        // kept records of the whole tile: one flush if they fit the staging area, else two half tiles
-        {
-            uint32_t c = (uint32_t)__popc(keep);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, WAVE);
-            if (lane_id() == 0) s_misc[8 + (threadIdx.x >> 6)] = c;
-        }
-        __syncthreads();
-        uint32_t kept = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; w++) kept += s_misc[8 + w];
-        const int halves = kept > (uint32_t)CAP ? 2 : 1;
-        for (int h = 0; h < halves; h++) {
-            const uint32_t mask = halves == 1 ? keep : (keep & (h ? 0xff00u : 0x00ffu));
-            if (h) {
-                __syncthreads();                           // first half copied out
-                for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
-                __syncthreads();
-            }
-#pragma unroll
-            for (int e = 0; e < E; e++) rank[e] = (mask & (1u << e)) ? atomicAdd(&s_cnt[dig[e]], 1u) : 0u;
-            __syncthreads();
-            block_scan_bins_t<NT>(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
-            const uint32_t total = s_misc[24];
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                if (mask & (1u << e)) {
-                    const uint32_t pos = s_cnt[dig[e]] + rank[e];
-                    s_key[pos] = key[e];
-                    s_pv[pos] = (dig[e] << 13) | (uint32_t)(threadIdx.x * E + e);
-                }
-            }
-            __syncthreads();
-            for (uint32_t j = threadIdx.x; j < total; j += NT) {
-                const uint32_t v = s_pv[j];
-                const uint32_t o = j + s_gdelta[v >> 13];
-                out_key[o] = s_key[j];
-                out_idx[o] = (uint32_t)(tile0 + (v & 0x1fffu));
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_scatter_text_accum: the partition pass of a rank that keeps only a small part of the suffixes (one of
-// N >= 4 prefix-bucket shards: 1/N of ~half of the positions).  An 8192-position tile then holds a few
-// hundred kept records, and zeroing / scanning ~640 digit counters plus the barriers around them for every
-// tile costs more than the records themselves.  Kept (key, index) pairs are therefore appended to the LDS
-// staging area tile after tile; only when the next (half) tile might not fit are they ranked by digit,
-// re-placed in digit order (every thread holds its records in registers meanwhile) and written out.
-// ---------------------------------------------------------------------------------------------
-template <int B>
-__global__ void __launch_bounds__(SPARSE_NT)
-k_scatter_text_accum(uint64_t n, const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
-                     uint32_t top_lo, uint32_t top_hi, const uint32_t* __restrict__ table,
-                     const uint32_t* __restrict__ binbase, uint64_t* __restrict__ out_key,
-                     uint32_t* __restrict__ out_idx)
-{
-    constexpr int NT = SPARSE_NT, E = SPARSE_E, CAP = ACCUM_CAP;
-    constexpr int TILEB = NT * E;
-    constexpr int PER = (CAP + NT - 1) / NT;               // staged records per thread at a flush (registers)
-    extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t NB = kp.nbins;
-    const uint32_t NBa = (NB + 3u) & ~3u;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_gbase = s_cnt + NBa;
-    uint32_t* s_gdelta = s_gbase + NBa;
-    uint64_t* s_key = reinterpret_cast<uint64_t*>(s_gdelta + NBa);      // CAP
-    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_key + CAP);         // CAP
-    uint32_t* s_misc = s_idx + CAP;                                      // 32
-    uint16_t* s_rm = reinterpret_cast<uint16_t*>(s_misc + 32);           // raw_bins
-
-    const uint32_t raw_mask = kp.raw_bins - 1;
-    const uint32_t* row = table + (size_t)blockIdx.x * NB;
-    for (uint32_t i = threadIdx.x; i < NB; i += NT) s_gbase[i] = row[i] + binbase[i];
-    const uint16_t* s_remap = nullptr;
-    if (gremap) {
-        for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += NT) s_rm[i] = gremap[i];
-        s_remap = s_rm;
-    }
-    uint32_t pending = 0;                                  // staged records (the same value in every thread)
-
-    auto flush = [&]() {
-        __syncthreads();                                   // appended records are visible
-        for (uint32_t i = threadIdx.x; i < NB; i += NT) s_cnt[i] = 0;
-        uint64_t rk[PER];
-        uint32_t ri[PER], rd[PER], rr[PER];
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const uint32_t j = threadIdx.x + (uint32_t)k * NT;
-            rk[k] = 0; ri[k] = 0;
-            if (j < pending) { rk[k] = s_key[j]; ri[k] = s_idx[j]; }
-            rd[k] = digit_of(rk[k], shift, raw_mask, s_remap);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; k++)
-            rr[k] = (threadIdx.x + (uint32_t)k * NT < pending) ? atomicAdd(&s_cnt[rd[k]], 1u) : 0u;
-        __syncthreads();
-        block_scan_bins_t<NT>(s_cnt, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            if (threadIdx.x + (uint32_t)k * NT < pending) {
-                const uint32_t pos = s_cnt[rd[k]] + rr[k];
-                s_key[pos] = rk[k];
-                s_idx[pos] = ri[k];
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < pending; j += NT) {
-            const uint64_t k = s_key[j];
-            const uint32_t o = j + s_gdelta[digit_of(k, shift, raw_mask, s_remap)];
-            out_key[o] = k;
-            out_idx[o] = s_idx[j];
-        }
-        __syncthreads();                                   // the staging area is free again
-        pending = 0;
-    };
-
-    // keys and shard filter of one tile; called again after a flush so that no key is live across it
-    auto tile_keys16 = [&](uint64_t tile0, uint64_t (&key)[E], uint32_t& keep) {
-        build_keys_packed_t<B, E>(kp.packed, tile0 + (uint64_t)threadIdx.x * E, kp.elig_codes, key, keep);
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t top = (uint32_t)(key[e] >> kp.top_shift) & raw_mask;
-            if (!(top >= top_lo && top < top_hi)) keep &= ~(1u << e);
-        }
-    };
-    auto append = [&](uint64_t tile0, const uint64_t (&key)[E], uint32_t bits, int first, uint32_t at) {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            if (e >= first && (bits & (1u << e))) {
-                s_key[at] = key[e];
-                s_idx[at] = (uint32_t)(tile0 + (uint64_t)threadIdx.x * E + (uint32_t)e);
-                at++;
-            }
-        }
-    };
-
-    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
-    const uint64_t c1 = min(c0 + chunk, n);
-    __syncthreads();
-    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
-        uint64_t key[E];
-        uint32_t keep;
-        tile_keys16(tile0, key, keep);
-        // kept records of the two half tiles, packed as lo | hi << 16, scanned over the workgroup
-        const uint32_t mine = (uint32_t)__popc(keep & 0x00ffu) | ((uint32_t)__popc(keep & 0xff00u) << 16);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, WAVE);
-            if ((int)lane_id() >= o) incl += t;
-        }
-        if (lane_id() == 63) s_misc[8 + (threadIdx.x >> 6)] = incl;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; w++) {
-            const uint32_t t = s_misc[8 + w];
-            if (w < (int)(threadIdx.x >> 6)) before += t;
-            total += t;
-        }
-        const uint32_t excl = before + incl - mine;
-        const uint32_t t_lo = total & 0xffffu, t_hi = total >> 16;          // each <= 4096 <= CAP
-        const uint32_t x_lo = excl & 0xffffu, x_hi = excl >> 16;
-        if (pending + t_lo + t_hi > (uint32_t)CAP) {
-            flush();
-            tile_keys16(tile0, key, keep);
-        }
-        if (t_lo + t_hi <= (uint32_t)CAP) {
-            // both halves: the low half's records first, then the high half's
-            append(tile0, key, keep & 0x00ffu, 0, pending + x_lo);
-            append(tile0, key, keep & 0xff00u, 8, pending + t_lo + x_hi);
-            pending += t_lo + t_hi;
-        } else {                                           // a dense tile: one half at a time
-            append(tile0, key, keep & 0x00ffu, 0, pending + x_lo);
-            pending += t_lo;
-            flush();
-            tile_keys16(tile0, key, keep);
-            append(tile0, key, keep & 0xff00u, 8, pending + x_hi);
-            pending += t_hi;
-        }
-        __syncthreads();                                   // s_misc is reused by the next tile
-    }
-    if (pending) flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1363,7 +1103,7 @@ __device__ __forceinline__ void match_digit_t(uint32_t d, int nbits, bool valid,
     }
 }
 
-template <bool HAS_SEG, int NT, int E, int NBITS, bool DIAG>
+template <bool HAS_SEG, int NT, int E, int NBITS>
 __global__ void __launch_bounds__(NT)
 k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict__ in_idx,
                 const uint32_t* __restrict__ in_seg, uint32_t m, uint32_t nbins, int nbits,
@@ -1371,19 +1111,8 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 int shift, int digit_from_seg, uint32_t chunk,
                 const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
                 uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx,
-                uint32_t* __restrict__ out_seg, int ablate, unsigned long long* __restrict__ stamps)
+                uint32_t* __restrict__ out_seg)
 {
-    // DIAG instances only (SUFR_HIP_PAIRS_ABLATE): ablation switches, and with bit 16 thread 0 accumulates
-    // s_memtime deltas per phase into stamps[]; the production instances carry none of this
-    if (!DIAG) ablate = 0;
-    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamping = DIAG && (ablate & 16) && threadIdx.x == 0;
-#define SUFR_STAMP(i)                                                        \
-    if (DIAG && stamping) {                                                  \
-        unsigned long long t_now = __builtin_amdgcn_s_memtime();             \
-        t_acc[i] += t_now - t_prev;                                          \
-        t_prev = t_now;                                                      \
-    }
     constexpr int TILEB = NT * E;
     constexpr int NW = NT / WAVE;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1414,7 +1143,6 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
     const int wv = threadIdx.x >> 6;
     const uint32_t ln = lane_id();
 
-    if (stamping) t_prev = __builtin_amdgcn_s_memtime();
     for (uint32_t tile0 = c0; tile0 < c1; tile0 += TILEB) {
         __syncthreads();  // previous tile's copy-out done before the union region is reused
         for (uint32_t i = threadIdx.x; i < (NW * NB + 1) / 2; i += NT)
@@ -1436,16 +1164,6 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
                 key[e] = 0; idx[e] = 0; sg[e] = 0;
             }
         }
-        if (ablate & 4) {          // timing experiment: loads only
-            uint64_t acc = 0;
-#pragma unroll
-            for (int e = 0; e < E; e++) acc ^= key[e] + idx[e];
-            if (acc == 0x123456789ull) out_key[0] = acc;
-            continue;
-        }
-        SUFR_STAMP(0)        // zero counters + issue loads
-        if (ablate & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        SUFR_STAMP(6)        // (diagnostic) wait for the tile's loads
         auto my = SUFR_LDS_VOLATILE(uint16_t, s_wcnt + (size_t)wv * NB);
         // digits of all E records first (independent LDS look-ups in flight together) ...
 #pragma unroll
@@ -1464,9 +1182,7 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
             rank[e] = before + lower;
             if (v && lower == 0) my[d] = (uint16_t)(before + __popc(mlo) + __popc(mhi));
         }
-        SUFR_STAMP(1)        // load wait + digits + ranking rounds
         __syncthreads();
-        SUFR_STAMP(2)        // barrier wait
         // per digit: exclusive prefix over waves (in place) and tile count
         for (uint32_t d = threadIdx.x; d < NB; d += NT) {
             uint32_t run = 0;
@@ -1481,7 +1197,6 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
         __syncthreads();
         block_scan_bins_t<NT>(s_tot, s_gbase, s_gdelta, NB, s_misc, s_misc + 24);
         const uint32_t total = s_misc[24];
-        SUFR_STAMP(3)        // wave prefix + bin scan
         // final tile-local position of every record (registers), before the union region is reused
 #pragma unroll
         for (int e = 0; e < E; e++)
@@ -1496,23 +1211,16 @@ k_scatter_pairs(const uint64_t* __restrict__ in_key, const uint32_t* __restrict_
             }
         }
         __syncthreads();
-        SUFR_STAMP(4)        // final positions + LDS staging
-        if (ablate & 2) continue;      // timing experiment: no copy-out
         for (uint32_t j = threadIdx.x; j < total; j += NT) {
             uint64_t k = s_key[j];
             uint32_t sgv = HAS_SEG ? s_seg[j] : 0u;
             uint32_t d = digit_from_seg ? ((sgv >> shift) & mask) : digit_of(k, shift, mask, s_remap);
             uint32_t o = j + s_gdelta[d];
-            if (ablate & 1) { if (k == 0x123456789ull && o == 77) out_idx[0] = 1; continue; }   // no global stores
             out_key[o] = k;
             out_idx[o] = s_idx[j];
             if (HAS_SEG) out_seg[o] = sgv;
         }
-        SUFR_STAMP(5)        // copy-out
     }
-    if (stamping)
-        for (int i = 0; i < 7; i++) atomicAdd(&stamps[i], t_acc[i]);
-#undef SUFR_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2218,5 +1926,6 @@ k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t co
 
 }  // namespace sufr
 
+#include "sufr_msd.inc"
 #include "sufr_launch.inc"
 #include "sufr_capi.inc"

@@ -16,9 +16,7 @@ from oracle_helper import GOLDEN, GOLDEN_CASES, check_sa_lcp_properties, naive_s
 
 pytestmark = pytest.mark.gpu
 
-# tuning knobs (SUFR_HIP_*) switch kernel variants: results must not change, variant assertions are skipped
 import os
-_KNOBS_SET = any(k.startswith("SUFR_HIP_") for k in os.environ)
 
 
 @pytest.fixture(scope="module")
@@ -212,8 +210,8 @@ def test_random_dna_sizes(ctx, oracle, n):
 
 
 def test_sparse_partition_kernel_both_flush_modes(ctx, oracle):
-    """At most ~55 % suffix starts selects k_scatter_text_sparse (8192-position tiles).  Dense stretches
-    overflow its record-sized staging area and are flushed as two half tiles; N-rich stretches fit in one."""
+    """The partition kernel takes 8192-position tiles: dense stretches overflow its record-sized staging area and
+    are flushed as two half tiles; N-rich stretches fit in one."""
     rng = np.random.default_rng(77)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     parts = [acgt[rng.integers(0, 4, size=70_000)]]                         # dense: two flushes per tile
@@ -224,8 +222,7 @@ def test_sparse_partition_kernel_both_flush_modes(ctx, oracle):
     raw = np.concatenate(parts + [np.frombuffer(b"$", dtype=np.uint8)])
     b = assert_matches_oracle(ctx, oracle, raw)
     assert b.num_suffixes <= 0.55 * raw.size
-    if not _KNOBS_SET:
-        assert b.stats.partition_variant == 1
+    assert b.stats.partition_variant == 3          # k_msd_scatter_text (bit-packed stream)
 
 
 def test_empty_text(ctx):
@@ -394,9 +391,7 @@ def test_device_api_and_shards_concatenate(oracle):
         for r in range(shards):
             psa, plcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, shard_index=r,
                                 num_shards=shards)
-            # 1/2 of ~47 % kept -> 8192-position tiles; 1/8 -> records accumulated over several tiles
-            if not _KNOBS_SET:
-                assert db.stats.partition_variant == (1 if shards == 2 else 2)
+            assert db.stats.partition_variant == 3
             psa = psa.cpu().numpy().view(np.uint32).copy(); plcp = plcp.cpu().numpy().view(np.uint32).copy()
             if parts_sa and psa.size:      # boundary stitch: find_lcp(prev.last, this.first) (893-902)
                 prev = next(p for p in reversed(parts_sa) if p.size)
