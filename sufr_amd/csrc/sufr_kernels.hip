@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "sufr_device.h"
 #include "sufr_runkey.h"
@@ -32,6 +33,12 @@ static_assert(RUN_TILE == (uint32_t)TILE, "run-end table granularity");
 // small helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t rec_key(const Rec& r) { return ((uint64_t)r.khi << 32) | r.klo; }
+__device__ __forceinline__ Rec make_rec(uint64_t key, uint32_t idx)
+{
+    Rec r; r.klo = (uint32_t)key; r.khi = (uint32_t)(key >> 32); r.idx = idx;
+    return r;
+}
 
 // Pointer to LDS that stays in the LDS address space: accesses compile to ds_read/ds_write, which one wave
 // issues and completes in order.  (A plain `volatile T*` to a __shared__ object becomes a generic pointer
@@ -900,7 +907,7 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
                const uint16_t* __restrict__ gremap, KeyParams kp, int shift, uint64_t chunk,
                uint32_t top_lo, uint32_t top_hi,
                const uint32_t* __restrict__ table, const uint32_t* __restrict__ binbase,
-               uint64_t* __restrict__ out_key, uint32_t* __restrict__ out_idx)
+               Rec* __restrict__ out)
 {
     constexpr int TILEB = NT * E;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1004,8 +1011,7 @@ k_scatter_text(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __r
             const uint32_t pe = s_idx[j];
             const uint32_t slot = pe >> 12, d = pe & 0xfffu;
             const uint32_t o = j + s_gdelta[d];
-            out_key[o] = s_key[slot];
-            out_idx[o] = (uint32_t)(tile0 + slot);
+            out[o] = make_rec(s_key[slot], (uint32_t)(tile0 + slot));
         }
     }
 }
@@ -1658,7 +1664,7 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
 // new level: slot t of the new active array takes the record src = heads[k] + (t - start[k])
 template <bool DEEP>
 __global__ void __launch_bounds__(256)
-k_build_level(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ opos,
+k_build_level(const uint32_t* __restrict__ idx, uint32_t istride, const uint32_t* __restrict__ opos,
               const uint32_t* __restrict__ heads, const uint32_t* __restrict__ start, uint32_t L,
               uint32_t m_new, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
               uint32_t* __restrict__ opos_new)
@@ -1671,7 +1677,7 @@ k_build_level(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ opo
         if (start[mid] <= t) lo = mid; else hi = mid;
     }
     uint32_t src = heads[lo] + (t - start[lo]);
-    idx_new[t] = idx[src];
+    idx_new[t] = idx[(size_t)src * istride];     // istride 3: the index field of 12-byte records
     seg_new[t] = lo;
     opos_new[t] = DEEP ? opos[src] : src;
 }
