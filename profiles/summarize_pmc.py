@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reduce rocprofv3 --pmc counter_collection.csv files to one row per (sufr kernel, counter):
-the value of the LARGEST dispatch of that kernel (the top-level launch over the whole genome) and the mean
-over all its dispatches."""
+the value of the dispatch with the LARGEST grid (the top-level launch over the whole genome), the mean over all
+its dispatches and the largest value of any dispatch (kernels whose grid is fixed: the heavy launch)."""
 import csv
 import glob
 import sys
@@ -9,7 +9,7 @@ from collections import defaultdict
 
 out, dirs = sys.argv[1], sys.argv[2:]
 best = {}
-acc = defaultdict(lambda: [0.0, 0])
+acc = defaultdict(lambda: [0.0, 0, 0.0])
 for d in dirs:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -19,13 +19,13 @@ for d in dirs:
             short = name.split("(")[0].replace("void ", "")
             key = (short, r["Counter_Name"])
             v = float(r["Counter_Value"]); g = int(r["Grid_Size"])
-            a = acc[key]; a[0] += v; a[1] += 1
+            a = acc[key]; a[0] += v; a[1] += 1; a[2] = max(a[2], v)
             if key not in best or g > best[key][0]:
                 best[key] = (g, v)
 with open(out, "w", newline="") as fh:
     w = csv.writer(fh)
-    w.writerow(["kernel", "counter", "largest_dispatch_grid", "largest_dispatch_value", "mean_value", "dispatches"])
+    w.writerow(["kernel", "counter", "largest_dispatch_grid", "largest_dispatch_value", "mean_value", "dispatches", "max_value"])
     for key in sorted(best):
-        g, v = best[key]; s, c = acc[key]
-        w.writerow([key[0], key[1], g, v, s / c, c])
+        g, v = best[key]; s, c, mx = acc[key]
+        w.writerow([key[0], key[1], g, v, s / c, c, mx])
 print("wrote", out, len(best), "rows")
