@@ -198,6 +198,42 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx *ctx, const sufr_sequence_data *s
                                   const sufr_create_args *args, char *path_out, size_t path_out_len,
                                   sufr_hip_stats *stats);
 
+
+/* ---- several GPUs: shards by first-digit range, every shard written into its own range of the file ------------
+ * replaces: the partition loop of SufrBuilder::write (sufr_builder.rs:875-906: SA and LCP of partition i appended
+ * after those of the partitions before it, LCP[first of partition i > 0] := find_lcp(prev.last_suffix,
+ * first_suffix, text_len, 0)) for shards built on different devices.
+ *
+ * One process driving N devices: sufr_hip_create_from_sequence_multi / sufr_hip_create_file_multi build shard r
+ * of n_ctx on ctxs[r] (a host thread per context; contexts may share a device) and write ONE .sufr file, byte for
+ * byte the file of the single-GPU build.  --max-query-len / --seed-mask builds and texts that need u64 indices are
+ * built on ctxs[0] alone (their tie order crosses first-digit buckets).  stats: n_ctx entries or NULL.
+ *
+ * One process per GPU (torch.distributed / MPI ranks): every rank calls sufr_hip_shard_build, the ranks exchange
+ * their sufr_shard_info (24 bytes each: the only collective of the path), rank 0 calls sufr_write_frame, and after
+ * a barrier every rank calls sufr_hip_shard_write with the suffix count of the ranks before it. */
+typedef struct sufr_shard_info {
+    uint64_t num_suffixes;      /* suffixes of this shard */
+    uint64_t first_suffix;      /* SA[0] of the shard (undefined when it is empty) */
+    uint64_t last_suffix;       /* SA[num_suffixes - 1] */
+} sufr_shard_info;
+int sufr_hip_shard_build(sufr_hip_ctx *ctx, const sufr_sequence_data *seq, const sufr_create_args *args,
+                         uint32_t shard_index, uint32_t num_shards, sufr_shard_info *info, sufr_hip_stats *stats);
+/* creates / truncates `outfile` and writes the header and the name table of a file with total_suffixes suffixes */
+int sufr_write_frame(const char *outfile, const sufr_sequence_data *seq, const sufr_create_args *args,
+                     uint64_t total_suffixes, char *err, size_t errlen);
+/* streams the resident shard (num_suffixes entries) to its place, suffix_offset entries into the SA / LCP sections
+ * of the existing `outfile`; has_prev: LCP[0] of the shard is first set to the boundary LCP with prev_last_suffix;
+ * write_text: this rank also writes the normalised text (rank 0) */
+int sufr_hip_shard_write(sufr_hip_ctx *ctx, const sufr_sequence_data *seq, const sufr_create_args *args,
+                         const char *outfile, uint64_t num_suffixes, uint64_t total_suffixes,
+                         uint64_t suffix_offset, int has_prev, uint64_t prev_last_suffix, int write_text);
+int sufr_hip_create_from_sequence_multi(sufr_hip_ctx *const *ctxs, int n_ctx, const sufr_sequence_data *seq,
+                                        const sufr_create_args *args, char *path_out, size_t path_out_len,
+                                        sufr_hip_stats *stats);
+int sufr_hip_create_file_multi(sufr_hip_ctx *const *ctxs, int n_ctx, const sufr_create_args *args, char *path_out,
+                               size_t path_out_len, sufr_hip_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ TAG=${1:-q}; WL=${2:-human}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/quick_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-CMD="python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --placement-trials 1"
+CMD="python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --placement-trials 1"
 $CMD > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
 rm -rf /tmp/prof_kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $CMD > /tmp/prof_kt.log 2>&1
 cp $(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$WL.csv

@@ -55,6 +55,10 @@ class CreateArgs(C.Structure):
                 ("seed_mask", C.c_char_p), ("random_seed", C.c_uint64)]
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [("num_suffixes", C.c_uint64), ("first_suffix", C.c_uint64), ("last_suffix", C.c_uint64)]
+
+
 FLAG_DNA, FLAG_ALLOW_AMBIGUITY, FLAG_IGNORE_SOFTMASK, FLAG_RAW_TEXT = 1, 2, 4, 8
 
 # every symbol include/sufr_hip.h declares
@@ -63,6 +67,8 @@ EXPORTS = [
     "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
     "sufr_hip_sort_device_u64", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
     "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file", "sufr_hip_create_from_sequence",
+    "sufr_hip_shard_build", "sufr_write_frame", "sufr_hip_shard_write", "sufr_hip_create_from_sequence_multi",
+    "sufr_hip_create_file_multi",
 ]
 
 _lib = None
@@ -109,6 +115,23 @@ def lib() -> C.CDLL:
     L.sufr_write_file.restype = C.c_int
     L.sufr_hip_create_file.argtypes = [vp, C.POINTER(CreateArgs), cp, C.c_size_t, C.POINTER(Stats)]
     L.sufr_hip_create_file.restype = C.c_int
+    L.sufr_hip_create_from_sequence.argtypes = [vp, C.POINTER(SequenceData), C.POINTER(CreateArgs), cp, C.c_size_t,
+                                                C.POINTER(Stats)]
+    L.sufr_hip_create_from_sequence.restype = C.c_int
+    L.sufr_hip_shard_build.argtypes = [vp, C.POINTER(SequenceData), C.POINTER(CreateArgs), u32, u32,
+                                       C.POINTER(ShardInfo), C.POINTER(Stats)]
+    L.sufr_hip_shard_build.restype = C.c_int
+    L.sufr_write_frame.argtypes = [cp, C.POINTER(SequenceData), C.POINTER(CreateArgs), u64, cp, C.c_size_t]
+    L.sufr_write_frame.restype = C.c_int
+    L.sufr_hip_shard_write.argtypes = [vp, C.POINTER(SequenceData), C.POINTER(CreateArgs), cp, u64, u64, u64, C.c_int,
+                                       u64, C.c_int]
+    L.sufr_hip_shard_write.restype = C.c_int
+    L.sufr_hip_create_from_sequence_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(SequenceData),
+                                                      C.POINTER(CreateArgs), cp, C.c_size_t, C.POINTER(Stats)]
+    L.sufr_hip_create_from_sequence_multi.restype = C.c_int
+    L.sufr_hip_create_file_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(CreateArgs), cp, C.c_size_t,
+                                             C.POINTER(Stats)]
+    L.sufr_hip_create_file_multi.restype = C.c_int
     _lib = L
     return L
 

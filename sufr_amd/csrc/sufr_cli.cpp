@@ -13,6 +13,7 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/sufr_hip.h"
 
@@ -41,7 +42,9 @@ int usage(FILE* f)
             "  -t, --threads <THREADS>   Accepted for compatibility (the build runs on the GPU)\n"
             "  -l, --log <LOG>           Log level [possible values: info, debug]\n"
             "      --log-file <FILE>     Log file\n"
-            "      --device <ID>         HIP device ordinal [default: 0]\n\n"
+            "      --device <ID>         HIP device ordinal [default: 0]\n"
+            "      --devices <ID,ID,...> Build on several GPUs: the suffixes are split by first-digit range, every GPU\n"
+            "                            sorts its range and writes its slice of the one output file\n\n"
             "create options:\n"
             "  -n, --num-partitions <NUM_PARTS>  Subproblem count [default: 16]\n"
             "  -m, --max-query-len <CONTEXT>     Max context\n"
@@ -62,6 +65,7 @@ int main(int argc, char** argv)
     Log log;
     std::string log_file, input, output, seed_mask, delim = "%";
     int device = 0;
+    std::vector<int> devices;
     bool have_cmd = false, have_output = false, have_mask = false;
     sufr_create_args a;
     memset(&a, 0, sizeof a);
@@ -83,6 +87,20 @@ int main(int argc, char** argv)
         }
         else if (s == "--log-file") log_file = need(i, "--log-file");
         else if (s == "--device") device = atoi(need(i, "--device"));
+        else if (s == "--devices") {
+            std::string v = need(i, "--devices");
+            devices.clear();
+            for (size_t p = 0; p <= v.size();) {
+                size_t q = v.find(',', p);
+                if (q == std::string::npos) q = v.size();
+                if (q == p || v.substr(p, q - p).find_first_not_of("0123456789") != std::string::npos) {
+                    fprintf(stderr, "error: invalid value '%s' for '--devices <ID,ID,...>'\n", v.c_str());
+                    return 2;
+                }
+                devices.push_back(atoi(v.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+        }
         else if (!have_cmd && (s == "create" || s == "cr")) have_cmd = true;
         else if (!have_cmd) { fprintf(stderr, "error: unrecognized subcommand '%s' (this build provides `create`)\n", s.c_str()); return 2; }
         else if (s == "-n" || s == "--num-partitions") a.num_partitions = strtoull(need(i, "-n"), nullptr, 10);
@@ -115,11 +133,20 @@ int main(int argc, char** argv)
 
     // the device context (HIP initialisation, ~0.3 s) comes up while the sequence file is being read
     auto t0 = std::chrono::steady_clock::now();
+    if (devices.empty()) devices.push_back(device);
+    std::vector<sufr_hip_ctx*> ctxs(devices.size(), nullptr);
     sufr_hip_ctx* ctx = nullptr;
     std::string ctx_error;
     std::thread bring_up([&]() {
-        ctx = sufr_hip_create(device);
-        if (!ctx) ctx_error = sufr_hip_last_error(nullptr);   // thread-local in the library: read it here
+        for (size_t r = 0; r < devices.size(); r++) {
+            ctxs[r] = sufr_hip_create(devices[r]);
+            if (!ctxs[r]) {                                    // thread-local in the library: read it here
+                ctx_error = sufr_hip_last_error(nullptr);
+                for (size_t q = 0; q < r; q++) { sufr_hip_destroy(ctxs[q]); ctxs[q] = nullptr; }
+                return;
+            }
+        }
+        ctx = ctxs[0];
     });
     sufr_sequence_data sd;
     char rerr[512] = {0};
@@ -131,18 +158,29 @@ int main(int argc, char** argv)
         fprintf(stderr, "Error: %s\n", ctx_error.c_str());
         return 1;
     }
-    if (read_rc != 0) { fprintf(stderr, "Error: %s\n", rerr); sufr_hip_destroy(ctx); return 1; }
-    log.info("Using HIP device " + std::to_string(device));
+    auto destroy_all = [&]() { for (auto* c : ctxs) if (c) sufr_hip_destroy(c); };
+    if (read_rc != 0) { fprintf(stderr, "Error: %s\n", rerr); destroy_all(); return 1; }
+    {
+        std::string ids;
+        for (size_t r = 0; r < devices.size(); r++) ids += (r ? "," : "") + std::to_string(devices[r]);
+        log.info(std::string("Using HIP device") + (devices.size() > 1 ? "s " : " ") + ids);
+    }
     char path[4096];
-    sufr_hip_stats st;
-    memset(&st, 0, sizeof st);
-    int rc = sufr_hip_create_from_sequence(ctx, &sd, &a, path, sizeof path, &st);
+    std::vector<sufr_hip_stats> sts(devices.size());
+    memset(sts.data(), 0, sts.size() * sizeof(sufr_hip_stats));
+    int rc = sufr_hip_create_from_sequence_multi(ctxs.data(), (int)ctxs.size(), &sd, &a, path, sizeof path, sts.data());
+    sufr_hip_stats st = sts[0];
+    for (size_t r = 1; r < sts.size(); r++) {                  // totals over the shards; device times: the slowest
+        st.num_suffixes += sts[r].num_suffixes;
+        if (sts[r].ms_total > st.ms_total) st.ms_total = sts[r].ms_total;
+        if (sts[r].num_levels > st.num_levels) st.num_levels = sts[r].num_levels;
+    }
     st.host_read_s = (float)read_s;
     sufr_sequence_data_free(&sd);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != 0) {
         fprintf(stderr, "Error: %s\n", sufr_hip_last_error(ctx));
-        sufr_hip_destroy(ctx);
+        destroy_all();
         return 1;
     }
     log.info("Read input of len " + with_commas(st.text_len));
@@ -162,7 +200,7 @@ int main(int argc, char** argv)
     snprintf(buf, sizeof buf, "host phases: read %.3fs, H2D + build %.3fs, D2H + write %.3fs", st.host_read_s,
              st.host_build_s, st.host_write_s);
     log.debug(buf);
-    sufr_hip_destroy(ctx);
+    destroy_all();
     if (log.out != stdout) fclose(log.out);
     return 0;
 }

@@ -279,9 +279,89 @@ bool pwrite_all(int fd, const void* buf, size_t len, uint64_t off)
 
 extern "C" void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg);  // sufr_capi.inc
 extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t flags,
-                                        uint64_t max_query_len, const char* seed_mask, uint64_t* num_suffixes,
-                                        sufr_hip_stats* stats, int* device, const void** d_text,
-                                        const void** d_sa, const void** d_lcp);           // sufr_capi.inc
+                                        uint64_t max_query_len, const char* seed_mask, uint32_t shard_index,
+                                        uint32_t num_shards, uint64_t* num_suffixes, sufr_hip_stats* stats,
+                                        int* device, const void** d_text, const void** d_sa,
+                                        const void** d_lcp);                               // sufr_capi.inc
+extern "C" int sufr_hip_resident_ends_(sufr_hip_ctx* ctx, uint64_t s, uint64_t* first, uint64_t* last);
+extern "C" int sufr_hip_resident_stitch_(sufr_hip_ctx* ctx, uint64_t n, uint64_t prev_last, uint64_t* lcp_out);
+extern "C" int sufr_hip_resident_arrays_(sufr_hip_ctx* ctx, int* device, const void** d_text, const void** d_sa,
+                                         const void** d_lcp);
+
+namespace {
+
+// default output name: "<input file stem>.sufr" in the current directory (sufr/src/lib.rs:334-340)
+std::string output_name(const sufr_create_args* a)
+{
+    if (a->output) return a->output;
+    std::string in = a->input;
+    size_t slash = in.find_last_of('/');
+    std::string base = slash == std::string::npos ? in : in.substr(slash + 1);
+    size_t dot = base.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) base = base.substr(0, dot);
+    if (base.empty()) base = "out";
+    return base + ".sufr";
+}
+
+uint32_t build_flags(const sufr_create_args* a)
+{
+    uint32_t flags = SUFR_HIP_FLAG_RAW_TEXT;
+    if (a->is_dna) flags |= SUFR_HIP_FLAG_DNA;
+    if (a->allow_ambiguity) flags |= SUFR_HIP_FLAG_ALLOW_AMBIGUITY;
+    if (a->ignore_softmask) flags |= SUFR_HIP_FLAG_IGNORE_SOFTMASK;
+    return flags;
+}
+
+SufrLayout layout_of(const sufr_sequence_data& sd, const sufr_create_args* a, uint64_t num_suffixes)
+{
+    return sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, sd.seq_len, 4, num_suffixes,
+                       a->has_max_query_len, a->max_query_len, a->seed_mask, sd.start_positions, sd.num_sequences,
+                       (const char* const*)sd.sequence_names);
+}
+
+// Device arrays -> their place in the file: a few threads, each copying 32 MB pieces into its own pinned buffer and
+// pwrite()-ing them at their final offset.  On the test box the device-to-host side runs at ~37 GB/s and the page
+// cache takes ~10 GB/s however many threads write (a shared mapping of the file instead of pwrite measured the same).
+struct Section { const void* src; uint64_t bytes, file_off; };
+int stream_sections(int device, int fd, const std::vector<Section>& secs)
+{
+    struct Piece { const uint8_t* src; uint64_t len, off; };
+    std::vector<Piece> pieces;
+    const uint64_t PIECE = (uint64_t)32 << 20;
+    for (const Section& sc : secs)
+        for (uint64_t o = 0; o < sc.bytes; o += PIECE)
+            pieces.push_back({(const uint8_t*)sc.src + o, sc.bytes - o < PIECE ? sc.bytes - o : PIECE, sc.file_off + o});
+    if (pieces.empty()) return 0;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    unsigned W = host_threads(12);
+    if (const char* e = getenv("SUFR_WRITE_THREADS")) if (atoi(e) > 0) W = (unsigned)atoi(e);
+    if (W > pieces.size()) W = (unsigned)pieces.size();
+    auto worker = [&]() {
+        void* pin = nullptr;
+        hipStream_t st = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, PIECE, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            failed = 1;
+            if (pin) (void)hipHostFree(pin);
+            return;
+        }
+        for (size_t i; !failed && (i = next.fetch_add(1)) < pieces.size();) {
+            const Piece& pc = pieces[i];
+            if (hipMemcpyAsync(pin, pc.src, pc.len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { failed = 1; break; }
+            if (!pwrite_all(fd, pin, pc.len, pc.off)) { failed = 2; break; }
+        }
+        (void)hipStreamDestroy(st);
+        (void)hipHostFree(pin);
+    };
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < W; w++) th.emplace_back(worker);
+    for (auto& x : th) x.join();
+    return failed;        // 0 ok, 1 device-to-host copy failed, 2 write failed
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -466,15 +546,146 @@ int sufr_write_file(const char* path, int is_dna, int allow_ambiguity, int ignor
     Out o;
     o.f = fopen(path, "wb");
     if (!o.f) { put_err(err, errlen, std::string(path) + ": " + strerror(errno)); return SUFR_HIP_E_IO; }
-    static char iobuf[1 << 20];
-    setvbuf(o.f, iobuf, _IOFBF, sizeof iobuf);
+    std::vector<char> iobuf(1 << 20);                  // per call: concurrent writers must not share a stdio buffer
+    setvbuf(o.f, iobuf.data(), _IOFBF, iobuf.size());
     o.raw(L.head.data(), L.head.size());
     o.raw(norm_text, text_len);
     o.raw(sa, (size_t)(num_suffixes * (uint64_t)index_width));
     o.raw(lcp, (size_t)(num_suffixes * (uint64_t)index_width));
     o.raw(L.tail.data(), L.tail.size());
     if (fclose(o.f) != 0) o.bad = true;
-    if (o.bad) { put_err(err, errlen, std::string(path) + ": write failed"); return SUFR_HIP_E_IO; }
+    if (o.bad) {
+        (void)unlink(path);                            // no valid header over short sections left behind
+        put_err(err, errlen, std::string(path) + ": write failed");
+        return SUFR_HIP_E_IO;
+    }
+    return 0;
+}
+
+int sufr_write_frame(const char* outfile, const sufr_sequence_data* sd, const sufr_create_args* a,
+                     uint64_t total_suffixes, char* err, size_t errlen)
+{
+    if (!outfile || !sd || !a) return SUFR_HIP_E_INVALID;
+    const SufrLayout L = layout_of(*sd, a, total_suffixes);
+    int fd = ::open(outfile, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { put_err(err, errlen, std::string(outfile) + ": " + strerror(errno)); return SUFR_HIP_E_IO; }
+    bool ok = pwrite_all(fd, L.head.data(), L.head.size(), 0) && pwrite_all(fd, L.tail.data(), L.tail.size(), L.tail_pos);
+    if (close(fd) != 0) ok = false;
+    if (!ok) { (void)unlink(outfile); put_err(err, errlen, std::string(outfile) + ": write failed"); return SUFR_HIP_E_IO; }
+    return 0;
+}
+
+int sufr_hip_shard_build(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const sufr_create_args* a,
+                         uint32_t shard_index, uint32_t num_shards, sufr_shard_info* info, sufr_hip_stats* stats)
+{
+    if (!ctx || !a || !sd || !sd->seq || !info) return SUFR_HIP_E_INVALID;
+    memset(info, 0, sizeof *info);
+    if (a->has_max_query_len && a->seed_mask) {                      // clap's conflicts_with; builder check 163-165
+        sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
+        return SUFR_HIP_E_CONFLICT;
+    }
+    if (sd->seq_len >= 0xFFFFFFFFull) {                              // suffix_array.rs:461 selects u64 there
+        sufr_hip_set_error_(ctx, "text_len >= 2^32 - 1 needs 64-bit indices (not built yet)");
+        return SUFR_HIP_E_UNSUPPORTED;
+    }
+    uint64_t s = 0;
+    int rc = sufr_hip_build_resident_(ctx, sd->seq, sd->seq_len, build_flags(a),
+                                      a->has_max_query_len ? a->max_query_len : 0, a->seed_mask, shard_index,
+                                      num_shards, &s, stats, nullptr, nullptr, nullptr, nullptr);
+    if (rc != 0) return rc;
+    info->num_suffixes = s;
+    if (s && (rc = sufr_hip_resident_ends_(ctx, s, &info->first_suffix, &info->last_suffix))) return rc;
+    return 0;
+}
+
+int sufr_hip_shard_write(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const sufr_create_args* a,
+                         const char* outfile, uint64_t num_suffixes, uint64_t total_suffixes, uint64_t suffix_offset,
+                         int has_prev, uint64_t prev_last_suffix, int write_text)
+{
+    if (!ctx || !a || !sd || !outfile) return SUFR_HIP_E_INVALID;
+    int rc;
+    if (has_prev && num_suffixes && (rc = sufr_hip_resident_stitch_(ctx, sd->seq_len, prev_last_suffix, nullptr))) return rc;
+    int device = 0;
+    const void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr;
+    if ((rc = sufr_hip_resident_arrays_(ctx, &device, &d_text, &d_sa, &d_lcp))) return rc;
+    const SufrLayout L = layout_of(*sd, a, total_suffixes);
+    int fd = ::open(outfile, O_WRONLY);
+    if (fd < 0) { sufr_hip_set_error_(ctx, (std::string(outfile) + ": " + strerror(errno)).c_str()); return SUFR_HIP_E_IO; }
+    std::vector<Section> secs;
+    if (write_text) secs.push_back({d_text, sd->seq_len, L.text_pos});
+    secs.push_back({d_sa, num_suffixes * 4, L.sa_pos + suffix_offset * 4});
+    secs.push_back({d_lcp, num_suffixes * 4, L.lcp_pos + suffix_offset * 4});
+    int failed = stream_sections(device, fd, secs);
+    if (close(fd) != 0 && !failed) failed = 2;
+    if (failed) {
+        sufr_hip_set_error_(ctx, failed == 2 ? (std::string(outfile) + ": write failed").c_str()
+                                             : "device-to-host copy of the arrays failed");
+        return failed == 2 ? SUFR_HIP_E_IO : SUFR_HIP_E_HIP;
+    }
+    return 0;
+}
+
+// One process, several GPUs: shard r of n_ctx is built on ctxs[r] (a thread per context), then every context
+// streams its SA / LCP slice to  sa_pos + 4 * (suffixes of the shards before it)  -- the multi-writer form of
+// SufrBuilder::write (sufr_builder.rs:875-906); the first LCP of every shard but the first is the boundary fix
+// 893-902, computed on that shard's device.  Contexts may share a device (tests: N shards on one GPU).
+int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, const sufr_sequence_data* sdp,
+                                        const sufr_create_args* a, char* path_out, size_t path_out_len,
+                                        sufr_hip_stats* stats)
+{
+    if (!ctxs || n_ctx < 1 || !a || !a->input || !sdp || !sdp->seq) return SUFR_HIP_E_INVALID;
+    for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return SUFR_HIP_E_INVALID;
+    sufr_hip_ctx* ctx0 = ctxs[0];
+    const sufr_sequence_data& sd = *sdp;
+    const std::string outfile = output_name(a);
+    if (path_out && path_out_len) snprintf(path_out, path_out_len, "%s", outfile.c_str());
+    if (sd.seq_len >= 0xFFFFFFFFull || a->has_max_query_len || a->seed_mask) n_ctx = 1;   // single-shard builds
+    const double t0 = now_s();
+    std::vector<sufr_shard_info> info(n_ctx);
+    std::vector<sufr_hip_stats> st(n_ctx);
+    std::vector<int> rcs(n_ctx, 0);
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n_ctx; r++)
+            th.emplace_back([&, r]() { rcs[r] = sufr_hip_shard_build(ctxs[r], &sd, a, (uint32_t)r, (uint32_t)n_ctx, &info[r], &st[r]); });
+        for (auto& x : th) x.join();
+    }
+    for (int r = 0; r < n_ctx; r++)
+        if (rcs[r]) { if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r])); return rcs[r]; }
+    const double t_built = now_s();
+    uint64_t total = 0;
+    std::vector<uint64_t> off(n_ctx, 0);
+    for (int r = 0; r < n_ctx; r++) { off[r] = total; total += info[r].num_suffixes; }
+    char err[512] = {0};
+    int rc = sufr_write_frame(outfile.c_str(), &sd, a, total, err, sizeof err);
+    if (rc != 0) { sufr_hip_set_error_(ctx0, err); return rc; }
+    {
+        std::vector<std::thread> th;
+        int prev = -1;                                   // last non-empty shard before r
+        for (int r = 0; r < n_ctx; r++) {
+            const int pv = prev;
+            th.emplace_back([&, r, pv]() {
+                rcs[r] = sufr_hip_shard_write(ctxs[r], &sd, a, outfile.c_str(), info[r].num_suffixes, total, off[r],
+                                              pv >= 0, pv >= 0 ? info[pv].last_suffix : 0, r == 0);
+            });
+            if (info[r].num_suffixes) prev = r;
+        }
+        for (auto& x : th) x.join();
+    }
+    for (int r = 0; r < n_ctx; r++)
+        if (rcs[r]) {
+            (void)unlink(outfile.c_str());               // no valid header over missing sections left behind
+            if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r]));
+            return rcs[r];
+        }
+    if (stats) {
+        for (int r = 0; r < n_ctx; r++) {
+            stats[r] = st[r];
+            stats[r].host_read_s = 0.0f;                 // filled in by the callers that read the file
+            stats[r].host_build_s = (float)(t_built - t0);
+            stats[r].host_write_s = (float)(now_s() - t_built);
+        }
+    }
     return 0;
 }
 
@@ -482,115 +693,33 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* s
                                   char* path_out, size_t path_out_len, sufr_hip_stats* stats)
 {
     if (!ctx || !a || !a->input || !sdp || !sdp->seq) return SUFR_HIP_E_INVALID;
-    char err[512] = {0};
     const sufr_sequence_data& sd = *sdp;
-    int rc = 0;
-    const double t_read = now_s();
-    // default output name: "<input file stem>.sufr" in the current directory (sufr/src/lib.rs:334-340)
-    std::string outfile;
-    if (a->output) outfile = a->output;
-    else {
-        std::string in = a->input;
-        size_t slash = in.find_last_of('/');
-        std::string base = slash == std::string::npos ? in : in.substr(slash + 1);
-        size_t dot = base.find_last_of('.');
-        if (dot != std::string::npos && dot > 0) base = base.substr(0, dot);
-        if (base.empty()) base = "out";
-        outfile = base + ".sufr";
+    if (sd.seq_len < 0xFFFFFFFFull) {
+        // 32-bit indices: SA, LCP and the normalised text stay in HBM after the build and are streamed to the file
+        return sufr_hip_create_from_sequence_multi(&ctx, 1, sdp, a, path_out, path_out_len, stats);
     }
+    // u64 arrays (suffix_array.rs:461): host buffers
+    char err[512] = {0};
+    const std::string outfile = output_name(a);
     if (path_out && path_out_len) snprintf(path_out, path_out_len, "%s", outfile.c_str());
-    const uint64_t n = sd.seq_len;
-    const int width = n < 0xFFFFFFFFull ? 4 : 8;                     // suffix_array.rs:461
-    uint32_t flags = SUFR_HIP_FLAG_RAW_TEXT;
-    if (a->is_dna) flags |= SUFR_HIP_FLAG_DNA;
-    if (a->allow_ambiguity) flags |= SUFR_HIP_FLAG_ALLOW_AMBIGUITY;
-    if (a->ignore_softmask) flags |= SUFR_HIP_FLAG_IGNORE_SOFTMASK;
-    const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
     if (a->has_max_query_len && a->seed_mask) {                      // clap's conflicts_with; builder check 163-165
         sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
         return SUFR_HIP_E_CONFLICT;
     }
-    if (width == 4) {
-        // 32-bit indices: SA, LCP and the normalised text stay in HBM after the build and are streamed to the
-        // file by a few threads, each copying 32 MB pieces into its own pinned buffer and pwrite()-ing them
-        // at their final offset (every section's place in the file is known once s is).  On the test box
-        // the device-to-host side of this runs at ~37 GB/s and the page cache takes ~10 GB/s however many
-        // threads write (a shared mapping of the file instead of pwrite measured the same).
-        uint64_t s = 0;
-        int device = 0;
-        const void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr;
-        rc = sufr_hip_build_resident_(ctx, sd.seq, n, flags, mql, a->seed_mask, &s, stats, &device, &d_text, &d_sa,
-                                      &d_lcp);
-        if (rc != 0) return rc;
-        const double t_built = now_s();
-        const SufrLayout L = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, 4, s,
-                                         a->has_max_query_len, a->max_query_len, a->seed_mask, sd.start_positions,
-                                         sd.num_sequences, (const char* const*)sd.sequence_names);
-        int fd = ::open(outfile.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (fd < 0) {
-            sufr_hip_set_error_(ctx, (outfile + ": " + strerror(errno)).c_str());
-                return SUFR_HIP_E_IO;
-        }
-        struct Piece { const uint8_t* src; uint64_t len, off; };
-        std::vector<Piece> pieces;
-        const uint64_t PIECE = (uint64_t)32 << 20;
-        auto add = [&](const void* base, uint64_t bytes, uint64_t file_off) {
-            for (uint64_t o = 0; o < bytes; o += PIECE)
-                pieces.push_back({(const uint8_t*)base + o, bytes - o < PIECE ? bytes - o : PIECE, file_off + o});
-        };
-        add(d_text, n, L.text_pos);
-        add(d_sa, s * 4, L.sa_pos);
-        add(d_lcp, s * 4, L.lcp_pos);
-        std::atomic<size_t> next{0};
-        std::atomic<int> failed{0};
-        unsigned W = host_threads(12);
-        if (const char* e = getenv("SUFR_WRITE_THREADS")) if (atoi(e) > 0) W = (unsigned)atoi(e);
-        if (W > pieces.size()) W = (unsigned)(pieces.size() ? pieces.size() : 1);
-        auto worker = [&]() {
-            void* pin = nullptr;
-            hipStream_t st = nullptr;
-            if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, PIECE, hipHostMallocDefault) != hipSuccess ||
-                hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-                failed = 1;
-                if (pin) (void)hipHostFree(pin);
-                return;
-            }
-            for (size_t i; !failed && (i = next.fetch_add(1)) < pieces.size();) {
-                const Piece& pc = pieces[i];
-                if (hipMemcpyAsync(pin, pc.src, pc.len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess) { failed = 1; break; }
-                if (!pwrite_all(fd, pin, pc.len, pc.off)) { failed = 2; break; }
-            }
-            (void)hipStreamDestroy(st);
-            (void)hipHostFree(pin);
-        };
-        {
-            std::vector<std::thread> th;
-            for (unsigned w = 0; w < W; w++) th.emplace_back(worker);
-            if (!pwrite_all(fd, L.head.data(), L.head.size(), 0)) failed = 2;
-            if (!pwrite_all(fd, L.tail.data(), L.tail.size(), L.tail_pos)) failed = 2;
-            for (auto& x : th) x.join();
-        }
-        if (close(fd) != 0 && !failed) failed = 2;
-        if (failed) {
-            sufr_hip_set_error_(ctx, failed == 2 ? (outfile + ": write failed").c_str()
-                                                 : "device-to-host copy of the arrays failed");
-            rc = failed == 2 ? SUFR_HIP_E_IO : SUFR_HIP_E_HIP;
-        }
-        if (stats) {
-            stats->host_read_s = 0.0f;                         // filled in by sufr_hip_create_file
-            stats->host_build_s = (float)(t_built - t_read);
-            stats->host_write_s = (float)(now_s() - t_built);
-        }
-        return rc;
+    const uint64_t n = sd.seq_len;
+    if (n >= 0xFFFFFFFFull - (1ull << 24)) {                         // before any allocation: the device path's limit
+        sufr_hip_set_error_(ctx, "text_len >= 2^32 - 2^24 needs 64-bit device indices (not built yet)");
+        return SUFR_HIP_E_UNSUPPORTED;
     }
+    const int width = 8;
     std::vector<uint8_t> norm(n);
     uint64_t s = 0;
     void* sa = malloc((size_t)n * (size_t)width + 8);
     void* lcp = malloc((size_t)n * (size_t)width + 8);
     if (!sa || !lcp) { free(sa); free(lcp); return SUFR_HIP_E_NOMEM; }
-    rc = sufr_hip_build_u64(ctx, sd.seq, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
-                            norm.data(), (uint64_t*)sa, (uint64_t*)lcp, n, &s, stats);
+    int rc = sufr_hip_build_u64(ctx, sd.seq, n, build_flags(a), a->has_max_query_len ? a->max_query_len : 0,
+                                a->seed_mask, a->num_partitions, a->random_seed, norm.data(), (uint64_t*)sa,
+                                (uint64_t*)lcp, n, &s, stats);
     if (rc == 0) {
         rc = sufr_write_file(outfile.c_str(), a->is_dna, a->allow_ambiguity, a->ignore_softmask, norm.data(), n,
                              width, sa, lcp, s, a->has_max_query_len, a->max_query_len, a->seed_mask,
@@ -616,6 +745,23 @@ int sufr_hip_create_file(sufr_hip_ctx* ctx, const sufr_create_args* a, char* pat
     const double t_read = now_s();
     rc = sufr_hip_create_from_sequence(ctx, &sd, a, path_out, path_out_len, stats);
     if (stats) stats->host_read_s = (float)(t_read - t_start);
+    sufr_sequence_data_free(&sd);
+    return rc;
+}
+
+int sufr_hip_create_file_multi(sufr_hip_ctx* const* ctxs, int n_ctx, const sufr_create_args* a, char* path_out,
+                               size_t path_out_len, sufr_hip_stats* stats)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0] || !a || !a->input) return SUFR_HIP_E_INVALID;
+    char err[512] = {0};
+    sufr_sequence_data sd;
+    const double t_start = now_s();
+    int rc = sufr_read_sequence_file(a->input, a->sequence_delimiter ? a->sequence_delimiter : (uint8_t)'%', &sd,
+                                     err, sizeof err);
+    if (rc != 0) { sufr_hip_set_error_(ctxs[0], err); return rc; }
+    const double t_read = now_s();
+    rc = sufr_hip_create_from_sequence_multi(ctxs, n_ctx, &sd, a, path_out, path_out_len, stats);
+    if (stats) stats[0].host_read_s = (float)(t_read - t_start);
     sufr_sequence_data_free(&sd);
     return rc;
 }

@@ -1922,6 +1922,31 @@ k_mask_lcp(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
     lcp[r] = c;
 }
 
+// Exact LCP of two suffixes of the device text: find_lcp(a, b, text_len, 0) of write()'s boundary fix
+// (sufr_builder.rs:893-902), for the first record of a shard against the last record of the shard before it.
+// One workgroup, 4096 characters per round.
+__global__ void __launch_bounds__(256)
+k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b, unsigned long long* __restrict__ out)
+{
+    __shared__ uint32_t s_first;
+    const uint64_t lim = n - (a > b ? a : b);          // characters both suffixes have
+    for (uint64_t k = 0;; k += 4096) {
+        if (threadIdx.x == 0) s_first = 0xffffffffu;
+        __syncthreads();
+        const uint64_t o = k + (uint64_t)threadIdx.x * 16;
+        uint32_t m = 16;
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint64_t q = o + i;
+            if (q >= lim || text[a + q] != text[b + q]) { m = i; break; }
+        }
+        if (m < 16) atomicMin(&s_first, threadIdx.x * 16 + m);
+        __syncthreads();
+        const uint32_t f = s_first;
+        __syncthreads();
+        if (f != 0xffffffffu) { if (threadIdx.x == 0) *out = k + f; return; }
+    }
+}
+
 // widen u32 results for the u64-index ABI (texts below 2^32-1 only)
 __global__ void __launch_bounds__(256)
 k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)

@@ -54,3 +54,43 @@ def stitched_first_lcp(boundaries: List[Boundary], rank: int,
             return k + int(neq[0])
         k += m
         step = min(step * 4, 1 << 20)
+
+
+def write_plan(boundaries: List[Boundary], rank: int):
+    """Where rank `rank` writes in the one output file and what it stitches: (suffix offset of its slice, suffixes
+    of the whole file, has_prev, last suffix of the nearest non-empty shard before it) -- the multi-writer form of
+    the partition loop of SufrBuilder::write (sufr_builder.rs:875-906)."""
+    total = sum(b[2] for b in boundaries)
+    offset = output_offset(boundaries, rank)
+    prev = [r for r in range(rank) if boundaries[r][2] > 0]
+    has_prev = bool(prev) and boundaries[rank][2] > 0
+    return offset, total, has_prev, (boundaries[prev[-1]][1] if has_prev else 0)
+
+
+def create_sharded(ctx, seq, args, outfile: str, rank: int, world: int, dist, device):
+    """`sufr create` with one process per GPU: this rank builds shard `rank` of `world` (C ABI:
+    sufr_hip_shard_build), the ranks all_gather {first, last, count} (24 bytes each -- the only collective), rank 0
+    lays out the file (sufr_write_frame), and after a barrier every rank streams its SA / LCP slice to its own range
+    (sufr_hip_shard_write, which also sets the slice's first LCP to the boundary LCP).  seq: _lib.SequenceData, args:
+    _lib.CreateArgs.  Returns (boundaries, stats)."""
+    import ctypes as C
+    import os
+    from . import _lib
+    L = _lib.lib()
+    info = _lib.ShardInfo(); st = _lib.Stats()
+    ctx.check(L.sufr_hip_shard_build(ctx.handle, C.byref(seq), C.byref(args), rank, world, C.byref(info), C.byref(st)))
+    bounds = exchange_boundaries(int(info.first_suffix), int(info.last_suffix), int(info.num_suffixes), device, dist)
+    offset, total, has_prev, prev_last = write_plan(bounds, rank)
+    path = os.fsencode(outfile)
+    if rank == 0:
+        err = C.create_string_buffer(512)
+        rc = L.sufr_write_frame(path, C.byref(seq), C.byref(args), total, err, len(err))
+        if rc != 0:
+            raise _lib.SufrHipError(rc, err.value.decode())
+    if dist is not None and dist.is_initialized() and world > 1:
+        dist.barrier()
+    ctx.check(L.sufr_hip_shard_write(ctx.handle, C.byref(seq), C.byref(args), path, int(info.num_suffixes), total,
+                                     offset, int(has_prev), prev_last, int(rank == 0)))
+    if dist is not None and dist.is_initialized() and world > 1:
+        dist.barrier()
+    return bounds, st

@@ -26,6 +26,9 @@ class SufrBuilder:
 
     def __init__(self, args: SufrBuilderArgs, index_width: Optional[int] = None, ctx: Optional[_lib.Context] = None,
                  write: bool = True):
+        # SufrBuilder::new bails when both are Some(..) -- Some(0) included (sufr_builder.rs:163-165)
+        if args.max_query_len is not None and args.seed_mask is not None:
+            raise _lib.SufrHipError(-8, "Cannot use max_query_len and seed_mask together")
         L = _lib.lib()
         raw = np.frombuffer(args.text, dtype=np.uint8) if not isinstance(args.text, np.ndarray) else \
             np.ascontiguousarray(args.text, dtype=np.uint8)

@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, out_path):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -58,6 +58,38 @@ def _worker(rank, world, port, q):
         if rank == 0:
             assert np.array_equal(np.concatenate([g[0] for g in gathered]), sa)
             assert np.array_equal(np.concatenate([g[1] for g in gathered]), lcp)
+        # ---- the multi-writer file (sufr_builder.rs:875-906 with one writer per shard): rank 0 lays the file out
+        # through the C ABI (sufr_write_frame: header + name table, host code only), every rank writes its slice
+        # at  sa_pos + 4 * (suffixes of the ranks before it);  the result must be the single-writer file
+        import ctypes as C
+        import struct
+        from sufr_amd import _lib
+        from sufr_amd.cli import create_args
+        offset, total, has_prev, prev_last = shards.write_plan(bounds, rank)
+        assert total == sa.size and offset == lo
+        assert has_prev == (rank > 0 and my_sa.size > 0) and (not has_prev or prev_last == int(sa[lo - 1]))
+        names = (C.c_char_p * 2)(b"chr_one", b"2")
+        starts = (C.c_uint64 * 2)(0, 40_000)
+        sd = _lib.SequenceData(norm.ctypes.data_as(C.POINTER(C.c_uint8)), norm.size, starts, names, 2)
+        args = create_args("in.fa", out_path, is_dna=True, ignore_softmask=True)
+        if rank == 0:
+            err = C.create_string_buffer(512)
+            assert _lib.lib().sufr_write_frame(out_path.encode(), C.byref(sd), C.byref(args), total, err, len(err)) == 0
+        dist.barrier()
+        fd = os.open(out_path, os.O_WRONLY)
+        with open(out_path, "rb") as fh:
+            head = fh.read(36)
+        text_pos, sa_pos, lcp_pos = struct.unpack_from("<QQQ", head, 12)
+        if rank == 0:
+            os.pwrite(fd, norm.tobytes(), text_pos)
+        os.pwrite(fd, my_sa.astype("<u4").tobytes(), sa_pos + 4 * offset)
+        os.pwrite(fd, my_lcp.astype("<u4").tobytes(), lcp_pos + 4 * offset)
+        os.close(fd)
+        dist.barrier()
+        if rank == 0:
+            o.write_file(out_path + ".ref", is_dna=True, allow_ambiguity=False, ignore_softmask=True, norm_text=norm,
+                         sa=sa, lcp=lcp, sequence_starts=(0, 40_000), sequence_names=("chr_one", "2"))
+            assert open(out_path, "rb").read() == open(out_path + ".ref", "rb").read()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, f"{type(e).__name__}: {e}"))
@@ -66,11 +98,11 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_shard_boundary_exchange_and_stitch_gloo(world):
+def test_shard_boundary_exchange_and_stitch_gloo(world, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, str(tmp_path / "sharded.sufr"))) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]

@@ -92,6 +92,51 @@ def test_native_cli_binary_golden(tmp_path):
     assert r.returncode == 0 and (tmp_path / "1.sufr").read_bytes() == (GOLDEN / "expected" / "1.sufr").read_bytes()
 
 
+@pytest.mark.parametrize("name", ["2.sufr", "long_dna_sequence.sufr", "uniprot.sufr", "uniprot-masked.sufr"])
+def test_multi_device_create_is_byte_identical(tmp_path, name):
+    """`sufr --devices 0,0,0 create` (three shards, here on one GPU): every shard writes its own range of the one
+    file, the boundary LCPs are stitched on the device -- the bytes are those of the golden / single-GPU file.
+    (--seed-mask builds are single-shard by design: the call degrades to one context.)"""
+    case = dict(GOLDEN_CASES[name])
+    fa = GOLDEN / "inputs" / case.pop("fa")
+    delim = case.pop("delimiter", b"%").decode()
+    want = (GOLDEN / "expected" / name).read_bytes()
+    out = tmp_path / name
+    path, sts = sufr_amd.create(str(fa), str(out), sequence_delimiter=delim, devices=[0, 0, 0], **case)
+    assert path == str(out) and len(sts) == 3
+    assert out.read_bytes() == want
+    out2 = tmp_path / ("cli_" + name)
+    cmd = [str(sufr_amd.CLI_PATH), "--devices", "0,0", "create", "-o", str(out2), str(fa), "-D", delim]
+    for flag, opt in (("is_dna", "--dna"), ("allow_ambiguity", "-a"), ("ignore_softmask", "-i")):
+        if case.get(flag):
+            cmd.append(opt)
+    if case.get("seed_mask"):
+        cmd += ["-s", case["seed_mask"]]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out2.read_bytes() == want
+
+
+def test_multi_device_create_5mb_genome(tmp_path, oracle):
+    """2, 5 and 8 shards of a 5 Mb soft-masked genome with N runs: the file equals the single-context file."""
+    x, starts = synth.syn_human(5_000_000, seed=11)
+    fa = tmp_path / "g.fa"
+    body = x.numpy()[:-1]
+    cuts = list(starts) + [body.size + 1]
+    with open(fa, "wb") as f:
+        for i in range(len(starts)):
+            f.write(f">s{i}\n".encode() + body[cuts[i]:cuts[i + 1] - 1].tobytes() + b"\n")
+    one = tmp_path / "one.sufr"
+    sufr_amd.create(str(fa), str(one), is_dna=True, ignore_softmask=True)
+    for k in (2, 5, 8):
+        out = tmp_path / f"k{k}.sufr"
+        sufr_amd.create(str(fa), str(out), is_dna=True, ignore_softmask=True, devices=[0] * k)
+        assert out.read_bytes() == one.read_bytes(), k
+    ref = tmp_path / "ref.sufr"
+    oracle.create(str(fa), str(ref), is_dna=True, ignore_softmask=True)
+    assert one.read_bytes() == ref.read_bytes()
+
+
 def test_create_reports_an_unwritable_output(tmp_path):
     """"{filename}: {io error}" like SufrBuilder::write (sufr_builder.rs:820), exit code 1 from the binary"""
     bad = tmp_path / "no_such_dir" / "x.sufr"
@@ -631,53 +676,58 @@ def test_elegans_config_c3_properties(oracle):
     db.close()
 
 
+def test_elegans_config_c3_equals_oracle(oracle):
+    """BASELINE config C3 (100 Mb, 7 sequences, --dna -n 64): the whole SA and the whole LCP array equal the
+    oracle's, element for element (the oracle runs on all host cores: seconds on the GPU box)."""
+    x, _ = synth.syn_elegans(100_286_401, seed=2, device="cuda")
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True, raw_text=True, num_partitions=64)
+    norm = oracle.normalize(x.cpu().numpy(), False)
+    osa, olcp, _ = oracle.build(norm, is_dna=True, num_partitions=64, threads=os.cpu_count() or 1)
+    assert np.array_equal(sa.cpu().numpy().view(np.uint32), osa)
+    assert np.array_equal(lcp.cpu().numpy().view(np.uint32), olcp)
+    db.close()
+
+
+def test_human_prefix_400mb_section_hashes_equal_oracle(oracle):
+    """The first 400 Mb of the C4 stand-in (+ '$'), --dna --ignore-softmask -n 256: xxh64 of the SA section and of
+    the LCP section (the bytes `sufr create` writes) equal the hashes of the oracle's arrays (SURVEY 8d gate)."""
+    import xxhash
+    x, _ = synth.syn_human(3_100_000_000, seed=4, device="cuda")
+    x = x[:400_000_001].clone()
+    x[-1] = ord("$")
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True, ignore_softmask=True, raw_text=True, num_partitions=256)
+    norm = oracle.normalize(x.cpu().numpy(), True)
+    osa, olcp, _ = oracle.build(norm, is_dna=True, num_partitions=256, threads=os.cpu_count() or 1)
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    assert gsa.size == osa.size
+    assert xxhash.xxh64(gsa.tobytes()).hexdigest() == xxhash.xxh64(osa.tobytes()).hexdigest()
+    assert xxhash.xxh64(glcp.tobytes()).hexdigest() == xxhash.xxh64(olcp.tobytes()).hexdigest()
+    db.close()
+
+
 def test_human_config_c4_properties():
     """BASELINE config C4 size (3.1 Gb stand-in, --dna --ignore-softmask): size-independent properties checked
-    on the GPU itself -- SA is a permutation of the eligible positions (count, sum and a weighted checksum
-    against the eligibility mask), 3e5 sampled adjacent ranks are in order with the exact LCP (window of 512
-    characters; longer LCPs are checked for >= 511 agreement), and 8 shards concatenate to the same arrays."""
+    on the GPU itself (sufr_amd/verify.py) -- SA is a permutation of the eligible positions (count, sum, a
+    weighted checksum and an xor of hashes against the eligibility mask); 10^6 sampled adjacent ranks plus 10^5
+    sampled from the ranks with LCP >= 64 (the ones the levels beyond the packed key produce) are in order with
+    the EXACT LCP, however long (walked through megabase N runs); 8 shards concatenate to the same arrays."""
+    from sufr_amd import verify
     x, _ = synth.syn_human(3_100_000_000, seed=4, device="cuda")
-    n = x.numel()
     db = sufr_amd.DeviceBuilder(0)
     out_sa = torch.empty(1_530_000_000, dtype=torch.int32, device="cuda")
     out_lcp = torch.empty_like(out_sa)
     sa, lcp = db.sort(x, is_dna=True, ignore_softmask=True, raw_text=True, out_sa=out_sa, out_lcp=out_lcp)
     s = sa.numel()
-    lut = torch.arange(256, dtype=torch.uint8, device="cuda")
-    lut[97:123] = 78                                          # lowercase -> 'N' (sufr_builder.rs:144-160)
-    elig = torch.zeros(256, dtype=torch.bool, device="cuda")
-    for c in b"ACGT$":
-        elig[c] = True
-    # permutation of the eligible positions
-    cnt = 0; tot = 0; wtot = 0
-    for lo in range(0, n, 1 << 28):
-        blk = lut[x[lo:lo + (1 << 28)].long()]
-        m = elig[blk.long()]
-        pos = torch.arange(lo, lo + blk.numel(), device="cuda")[m]
-        cnt += int(m.sum()); tot += int(pos.sum()); wtot += int((pos * (pos % 1009)).sum())
-    assert cnt == s
-    p64 = sa.to(torch.int64) & 0xFFFFFFFF
-    M64 = (1 << 64) - 1                                       # the weighted sums wrap: compare modulo 2^64
-    assert int(p64.sum()) == tot and (int((p64 * (p64 % 1009)).sum()) & M64) == (wtot & M64)
-    assert int(lcp[0]) == 0
-    # order and exact LCP on sampled adjacent ranks
-    g = torch.Generator(device="cuda"); g.manual_seed(5)
-    W = 512
-    ar = torch.arange(W, device="cuda")
-    for _ in range(3):
-        pick = torch.randint(1, s, (100_000,), generator=g, device="cuda")
-        a = p64[pick - 1]; b = p64[pick]
-        want = lcp[pick].to(torch.int64) & 0xFFFFFFFF
-        ia = a[:, None] + ar[None, :]; ib = b[:, None] + ar[None, :]
-        ta = torch.where(ia < n, lut[x[ia.clamp(max=n - 1)].long()].to(torch.int16), torch.tensor(-1, dtype=torch.int16, device="cuda"))
-        tb = torch.where(ib < n, lut[x[ib.clamp(max=n - 1)].long()].to(torch.int16), torch.tensor(-1, dtype=torch.int16, device="cuda"))
-        diff = ta != tb
-        anyd = diff.any(1)
-        first = torch.where(anyd, diff.float().argmax(1), torch.full_like(pick, W))
-        short = want < W
-        assert bool(torch.all(first[short] == want[short])) and bool(torch.all(first[~short] == W))
-        fa = ta.gather(1, first.clamp(max=W - 1)[:, None])[:, 0]; fb = tb.gather(1, first.clamp(max=W - 1)[:, None])[:, 0]
-        assert bool(torch.all(fa[short] < fb[short]))
+    assert verify.check_permutation(x, sa, is_dna=True, ignore_softmask=True) == s
+    lut = verify.normalize_lut("cuda", True)
+    norm = torch.empty_like(x)
+    for lo in range(0, x.numel(), 1 << 28):
+        norm[lo:lo + (1 << 28)] = lut[x[lo:lo + (1 << 28)].long()]
+    got = verify.check_sampled_ranks(norm, sa, lcp, samples=1_000_000, deep_samples=100_000, deep_min_lcp=64, seed=5)
+    assert got["ranks"] == 1_100_000 and got["deep_ranks"] == 100_000 and got["max_lcp_checked"] > 10_000
+    del norm
     # 8 prefix-bucket shards: identical arrays apart from the stitched first LCP of shards 1..7
     full_sa, full_lcp = sa.clone(), lcp.clone()
     off = 0

@@ -193,6 +193,16 @@ def test_lcp_pair():
 
 
 @pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_builder_rejects_max_query_len_with_seed_mask_even_when_zero():
+    """SufrBuilder::new: `seed_mask.is_some() && max_query_len.is_some()` bails, Some(0) included
+    (sufr_builder.rs:163-165)."""
+    for mql in (0, 5):
+        a = sufr_amd.SufrBuilderArgs(text=b"ACGTACGT$", max_query_len=mql, seed_mask="101", is_dna=True,
+                                     sequence_starts=[0], sequence_names=["1"])
+        with pytest.raises(sufr_amd.SufrHipError, match="Cannot use max_query_len and seed_mask together"):
+            sufr_amd.SufrBuilder(a, write=False)
+
+
 def test_build_fails_loudly_without_gpu(tmp_path):
     assert sufr_amd.lib().sufr_hip_device_count() == 0
     with pytest.raises(sufr_amd.SufrHipError) as e:
