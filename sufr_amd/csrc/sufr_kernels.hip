@@ -1492,6 +1492,53 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         gid1 = act1 ? (uint32_t)ng1 : (0x10000u | (uint32_t)(64 + ln));
         lt0 = tie0; lt1 = tie1;
         if (TIES_OUT) break;                  // tie runs go to the dense tie level (k_build_ties)
+        // ---- pairs: two suffixes that still tie (and nobody else with them) are compared directly, eight
+        // characters per step, instead of being re-keyed ~20 characters per round: an exact duplicate of 100 kb is
+        // 10^5 such pairs with common prefixes of up to 10^5 characters (find_lcp's byte walk, sufr_builder.rs:
+        // 319-329, as a word walk).  The head lane of a pair does the walk; results travel through the LDS.
+        {
+            auto tbit = [&](int t) -> bool {
+                return t < 64 ? ((T0 >> t) & 1ull) != 0 : (t < 128 ? ((T1 >> (t - 64)) & 1ull) != 0 : false);
+            };
+            const bool ph0 = act0 && !tie0 && tbit(ln + 1) && !tbit(ln + 2);
+            const bool ph1 = act1 && !tie1 && tbit(64 + ln + 1) && !tbit(64 + ln + 2);
+            const bool ps0 = act0 && tie0 && !tbit(ln + 1) && ln >= 1 && !tbit(ln - 1);
+            const bool ps1 = act1 && tie1 && !tbit(64 + ln + 1) && !tbit(64 + ln - 1);
+            if (__ballot(ph0 || ph1) != 0ull) {
+                auto walk = [&](uint32_t slot, uint32_t mine, uint32_t dnew) {
+                    const uint32_t other = si[slot + 1];
+                    const uint64_t a = (uint64_t)mine + dnew, b = (uint64_t)other + dnew;
+                    const uint64_t lim = n - (a > b ? a : b);        // characters both suffixes have
+                    uint64_t k = 0;
+                    bool found = false;
+                    while (k + 64 <= lim && !found) {             // 64 characters per round trip, eight loads in flight per side
+                        uint64_t x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            x[u] = load_u64_unaligned(text + a + k + 8 * u) ^ load_u64_unaligned(text + b + k + 8 * u);
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            if (!found && x[u]) { k += 8 * u + (uint64_t)(__builtin_ctzll(x[u]) >> 3); found = true; }
+                        if (!found) k += 64;
+                    }
+                    while (!found && k + 8 <= lim) {
+                        const uint64_t x = load_u64_unaligned(text + a + k) ^ load_u64_unaligned(text + b + k);
+                        if (x) { k += (uint64_t)(__builtin_ctzll(x) >> 3); found = true; break; }
+                        k += 8;
+                    }
+                    if (!found) while (k < lim && text[a + k] == text[b + k]) k++;
+                    // the suffix that ends first (a proper prefix of the other) sorts first
+                    const bool mine_first = k == lim ? a > b : text[a + k] < text[b + k];
+                    si[slot] = mine_first ? mine : other;
+                    si[slot + 1] = mine_first ? other : mine;
+                    sg[slot + 1] = dnew + (uint32_t)k;
+                };
+                if (ph0) walk((uint32_t)ln, i0, dd0 + (plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b)));
+                if (ph1) walk((uint32_t)(64 + ln), i1, dd1 + (plain ? (uint32_t)kp.K : run_key_advance(k1, 64, kp.b)));
+                if (ph0 || ps0) { i0 = si[ln]; if (ps0) lcp0 = sg[ln]; act0 = false; gid0 = 0x10000u | (uint32_t)ln; lt0 = false; }
+                if (ph1 || ps1) { i1 = si[64 + ln]; if (ps1) lcp1 = sg[64 + ln]; act1 = false; gid1 = 0x10000u | (uint32_t)(64 + ln); lt1 = false; }
+            }
+        }
         // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
         if (act0) {
             dd0 += plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b);
