@@ -1331,6 +1331,59 @@ __device__ __forceinline__ int mask_next_set(uint64_t M0, uint64_t M1, int slot,
     return m ? 64 + __builtin_ctzll(m) : none;
 }
 
+#ifdef SUFR_HIP_PROBES
+__device__ unsigned long long g_walk_stats[4];       // pair walks, their characters, the longest, (spare)
+#endif
+
+// common prefix of suffixes a and b (positions in the text), 64 characters per round trip: find_lcp's byte walk
+// (sufr_builder.rs:319-329) as a word walk
+// A walk is blind to runs: two suffixes that continue with megabases of `N` are better served by a run key, which
+// crosses a run in one step.  In-kernel walks therefore stop after WALK_CAP characters; a pair / group that has not
+// parted by then stays tied, WALK_CAP characters deeper, and is keyed with a run key next.
+static constexpr uint32_t WALK_CAP = 4096;
+
+__device__ __forceinline__ uint64_t walk_lcp(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b,
+                                             uint64_t cap = ~0ull)
+{
+    uint64_t lim = n - (a > b ? a : b);              // characters both suffixes have
+    if (lim > cap) lim = cap;
+    uint64_t k = 0;
+    while (k + 64 <= lim) {
+        uint64_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = load_u64_unaligned(text + a + k + 8 * u) ^ load_u64_unaligned(text + b + k + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (x[u]) return k + 8 * u + (uint64_t)(__builtin_ctzll(x[u]) >> 3);
+        k += 64;
+    }
+    while (k < lim && text[a + k] == text[b + k]) k++;
+    return k;
+}
+
+// Walk keys: a member of a tie group keyed by its common prefix L with the group's FIRST member (the reference),
+// beyond the depth all members share.  A member that leaves the reference's text earlier than another is smaller than
+// it iff its character there is below the reference's: {below the reference, L ascending} < reference < {above, L
+// descending} -- the order of run tokens (sufr_runkey.h) with the reference in the place of the periodic extension.
+// Two members part after min(L, L') characters; equal keys share L characters.
+// The reference's own key stands for "agrees with the reference for WALK_CAP characters": members that do take it too
+// and stay tied with it, WALK_CAP characters deeper.
+static constexpr uint64_t WALK_MAX = (1ull << 62) - 1;
+__device__ __forceinline__ uint64_t walk_key(bool is_ref, bool below, uint64_t L)
+{
+    return is_ref ? (1ull << 62) : (below ? L : ((2ull << 62) | (WALK_MAX - L)));
+}
+__device__ __forceinline__ uint64_t walk_key_len(uint64_t k)
+{
+    const uint32_t cls = (uint32_t)(k >> 62);
+    return cls == 0 ? k : (cls == 1 ? (uint64_t)WALK_CAP : WALK_MAX - (k & WALK_MAX));
+}
+__device__ __forceinline__ uint32_t walk_key_common(uint64_t a, uint64_t b)
+{
+    const uint64_t la = walk_key_len(a), lb = walk_key_len(b);
+    return (uint32_t)(la < lb ? la : lb);
+}
+
 // TIES_OUT (top level): records that still tie after the first ranking (equal whole key) are not iterated
 // on here -- almost every window has a few of them, and re-keying them in place would keep 128 lanes busy
 // for the sake of two or three.  Instead the window's tie runs are written back in sorted order and
@@ -1352,6 +1405,12 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          uint32_t* idx_writeback, unsigned long long* __restrict__ wmask, uint32_t* __restrict__ wcnt,
          uint32_t ncross)
 {
+#ifdef SUFR_HIP_PROBES
+    const uint32_t popts = ncross >> 30;            // timing probes: 1 = no pair walk, 2 = no walk keys
+    ncross &= 0x3fffffffu;
+#else
+    constexpr uint32_t popts = 0;
+#endif
     __shared__ uint64_t sh_key[4][128];
     __shared__ uint32_t sh_idx[4][128];
     __shared__ uint32_t sh_gid[4][128];
@@ -1445,7 +1504,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     uint32_t gid0 = act0 ? (uint32_t)g0 : (0x10000u | (uint32_t)ln);
     uint32_t gid1 = act1 ? (uint32_t)g1 : (0x10000u | (uint32_t)(64 + ln));
 
-    bool plain = !DEEP;                       // format of the keys currently held
+    int ktype = DEEP ? 1 : 0;                 // keys currently held: 0 plain packed characters, 1 run keys, 2 walk keys
+    uint32_t extra0 = 0, extra1 = 0;          // characters a capped pair walk has matched beyond the key
     const uint64_t max_round = n + 8;        // distinct suffixes separate within n characters
     bool lt0 = false, lt1 = false;           // tie flags of the last ranking
     for (uint64_t round = 0; __ballot(act0 || act1) != 0ull && round < max_round; round++) {
@@ -1479,8 +1539,14 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         const bool same0 = act0 && (uint32_t)ln > gid0;
         const bool same1 = act1 && (uint32_t)(64 + ln) > gid1;
         const bool tie0 = same0 && q0 == k0, tie1 = same1 && q1 == k1;
-        if (same0 && !tie0) lcp0 = dd0 + (plain ? plain_key_common(q0, k0, kp.b, kp.K) : run_key_common(q0, k0, kp.b));
-        if (same1 && !tie1) lcp1 = dd1 + (plain ? plain_key_common(q1, k1, kp.b, kp.K) : run_key_common(q1, k1, kp.b));
+        auto common = [&](uint64_t a, uint64_t b2) -> uint32_t {
+            return ktype == 0 ? plain_key_common(a, b2, kp.b, kp.K) : (ktype == 1 ? run_key_common(a, b2, kp.b) : walk_key_common(a, b2));
+        };
+        auto advance = [&](uint64_t k) -> uint32_t {
+            return ktype == 0 ? (uint32_t)kp.K : (ktype == 1 ? run_key_advance(k, 64, kp.b) : (uint32_t)walk_key_len(k));
+        };
+        if (same0 && !tie0) lcp0 = dd0 + common(q0, k0);
+        if (same1 && !tie1) lcp1 = dd1 + common(q1, k1);
         const uint64_t T0 = __ballot(tie0), T1 = __ballot(tie1);
         // new group of a slot = nearest slot at or before it that does not tie with its predecessor
         const int ng0 = mask_prev_set(~T0, ~T1, ln), ng1 = mask_prev_set(~T0, ~T1, 64 + ln);
@@ -1504,51 +1570,78 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
             const bool ph1 = act1 && !tie1 && tbit(64 + ln + 1) && !tbit(64 + ln + 2);
             const bool ps0 = act0 && tie0 && !tbit(ln + 1) && ln >= 1 && !tbit(ln - 1);
             const bool ps1 = act1 && tie1 && !tbit(64 + ln + 1) && !tbit(64 + ln - 1);
-            if (__ballot(ph0 || ph1) != 0ull) {
+            if (!(popts & 1u) && __ballot(ph0 || ph1) != 0ull) {
                 auto walk = [&](uint32_t slot, uint32_t mine, uint32_t dnew) {
                     const uint32_t other = si[slot + 1];
                     const uint64_t a = (uint64_t)mine + dnew, b = (uint64_t)other + dnew;
                     const uint64_t lim = n - (a > b ? a : b);        // characters both suffixes have
-                    uint64_t k = 0;
-                    bool found = false;
-                    while (k + 64 <= lim && !found) {             // 64 characters per round trip, eight loads in flight per side
-                        uint64_t x[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            x[u] = load_u64_unaligned(text + a + k + 8 * u) ^ load_u64_unaligned(text + b + k + 8 * u);
-#pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            if (!found && x[u]) { k += 8 * u + (uint64_t)(__builtin_ctzll(x[u]) >> 3); found = true; }
-                        if (!found) k += 64;
+                    const uint64_t k = walk_lcp(text, n, a, b, WALK_CAP);
+                    if (k == WALK_CAP && k < lim) {                  // not parted yet: stays a pair, WALK_CAP deeper
+                        sg[slot] = 0xffffffffu; sg[slot + 1] = 0xffffffffu;
+                        return;
                     }
-                    while (!found && k + 8 <= lim) {
-                        const uint64_t x = load_u64_unaligned(text + a + k) ^ load_u64_unaligned(text + b + k);
-                        if (x) { k += (uint64_t)(__builtin_ctzll(x) >> 3); found = true; break; }
-                        k += 8;
-                    }
-                    if (!found) while (k < lim && text[a + k] == text[b + k]) k++;
                     // the suffix that ends first (a proper prefix of the other) sorts first
                     const bool mine_first = k == lim ? a > b : text[a + k] < text[b + k];
                     si[slot] = mine_first ? mine : other;
                     si[slot + 1] = mine_first ? other : mine;
+                    sg[slot] = 0u;
                     sg[slot + 1] = dnew + (uint32_t)k;
+#ifdef SUFR_HIP_PROBES
+                    atomicAdd(&g_walk_stats[0], 1ull); atomicAdd(&g_walk_stats[1], (unsigned long long)k);
+                    atomicMax(&g_walk_stats[2], (unsigned long long)k);
+#endif
                 };
-                if (ph0) walk((uint32_t)ln, i0, dd0 + (plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b)));
-                if (ph1) walk((uint32_t)(64 + ln), i1, dd1 + (plain ? (uint32_t)kp.K : run_key_advance(k1, 64, kp.b)));
-                if (ph0 || ps0) { i0 = si[ln]; if (ps0) lcp0 = sg[ln]; act0 = false; gid0 = 0x10000u | (uint32_t)ln; lt0 = false; }
-                if (ph1 || ps1) { i1 = si[64 + ln]; if (ps1) lcp1 = sg[64 + ln]; act1 = false; gid1 = 0x10000u | (uint32_t)(64 + ln); lt1 = false; }
+                if (ph0) walk((uint32_t)ln, i0, dd0 + advance(k0));
+                if (ph1) walk((uint32_t)(64 + ln), i1, dd1 + advance(k1));
+                if (ph0 || ps0) {
+                    const uint32_t v = sg[ln];
+                    if (v == 0xffffffffu) extra0 = WALK_CAP;
+                    else { i0 = si[ln]; if (ps0) lcp0 = v; act0 = false; gid0 = 0x10000u | (uint32_t)ln; lt0 = false; }
+                }
+                if (ph1 || ps1) {
+                    const uint32_t v = sg[64 + ln];
+                    if (v == 0xffffffffu) extra1 = WALK_CAP;
+                    else { i1 = si[64 + ln]; if (ps1) lcp1 = v; act1 = false; gid1 = 0x10000u | (uint32_t)(64 + ln); lt1 = false; }
+                }
             }
         }
         // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
-        if (act0) {
-            dd0 += plain ? (uint32_t)kp.K : run_key_advance(k0, 64, kp.b);
-            k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u, kp.packed);
+        // Run keys and walk keys take turns: a run key looks ~20 characters ahead (or across a whole run); if that
+        // did not part the group, its members are copies of something long -- the next key is the common prefix with
+        // the group's first member, found by a word walk, and the round after it looks at the characters behind it.
+        const bool walk_next = ktype == 1 && round >= 1 && !(popts & 2u) && __ballot(extra0 | extra1) == 0ull;
+        if (walk_next) {
+            // the reference: the member in the group's first slot (slots hold the sorted records by now)
+            auto wkey = [&](uint32_t mine, uint32_t ref, uint32_t d) -> uint64_t {
+                const uint64_t a = (uint64_t)mine + d, r2 = (uint64_t)ref + d;
+                const uint64_t lim = n - (a > r2 ? a : r2);
+                const uint64_t L = walk_lcp(text, n, a, r2, WALK_CAP);
+                if (L == WALK_CAP && L < lim) return walk_key(true, false, 0);      // agrees with the reference so far
+                const bool below = L == lim ? a > r2 : text[a + L] < text[r2 + L];
+                return walk_key(false, below, L);
+            };
+            if (act0) {
+                dd0 += advance(k0);
+                const uint32_t ref = si[gid0];
+                k0 = gid0 == (uint32_t)ln ? walk_key(true, false, 0) : wkey(i0, ref, dd0);
+            }
+            if (act1) {
+                dd1 += advance(k1);
+                const uint32_t ref = si[gid1];
+                k1 = gid1 == (uint32_t)(64 + ln) ? walk_key(true, false, 0) : wkey(i1, ref, dd1);
+            }
+            ktype = 2;
+        } else {
+            if (act0) {
+                dd0 += advance(k0) + extra0; extra0 = 0;
+                k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u, kp.packed);
+            }
+            if (act1) {
+                dd1 += advance(k1) + extra1; extra1 = 0;
+                k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u, kp.packed);
+            }
+            ktype = 1;
         }
-        if (act1) {
-            dd1 += plain ? (uint32_t)kp.K : run_key_advance(k1, 64, kp.b);
-            k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u, kp.packed);
-        }
-        plain = false;
     }
     if (TIES_OUT) {
         // describe this window's tie runs: members (M) and run heads (H); write the members back in order
@@ -2005,5 +2098,6 @@ k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t co
 }  // namespace sufr
 
 #include "sufr_msd.inc"
+#include "sufr_dbl.inc"
 #include "sufr_launch.inc"
 #include "sufr_capi.inc"

@@ -392,6 +392,43 @@ def test_many_near_identical_copies(ctx, oracle):
         assert_matches_oracle(ctx, oracle, x.numpy())
 
 
+def _copies_text(seed, n, seg_len, copies, *, n_run=0, spacing=None, mutate=0.0):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = acgt[rng.integers(0, 4, n)]
+    seg = acgt[rng.integers(0, 4, seg_len)].copy()
+    if n_run:
+        seg[seg_len // 3:seg_len // 3 + n_run] = ord("N")           # the copies share a masked stretch
+    spacing = spacing or (n - seg_len - 10) // copies
+    for k in range(copies):
+        c = seg.copy()
+        if mutate:
+            hit = rng.random(seg_len) < mutate
+            c[hit] = acgt[rng.integers(0, 4, int(hit.sum()))]
+        at = 5 + k * spacing
+        t[at:at + seg_len] = c
+    return np.concatenate([t, np.frombuffer(b"$", dtype=np.uint8)])
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=1_000_000, seg_len=20_000, copies=10),                   # groups of 10: walk keys inside k_finish
+    dict(n=2_000_000, seg_len=2_000, copies=300),                   # groups of 300: prefix doubling takes the level over
+    dict(n=2_000_000, seg_len=3_000, copies=200, n_run=50),         # ... with run keys among the rank keys (--dna: N starts no suffix)
+    dict(n=1_500_000, seg_len=4_000, copies=150, mutate=0.002),     # near-identical copies: groups split round by round
+    dict(n=600_000, seg_len=2_500, copies=200, spacing=2_500),      # a tandem array of a long unit (period >> 8)
+])
+def test_many_copies_of_a_long_repeat(ctx, oracle, case):
+    """Copies of a long segment tie for thousands of characters: ~20 characters per re-keying level would take
+    hundreds of levels.  Small groups are split by walk keys (common prefix with the group's first member), large
+    ones by prefix doubling over ranks with the LCPs filled in by the text-order pass (sufr_dbl.inc)."""
+    raw = _copies_text(77, **case)
+    b = assert_matches_oracle(ctx, oracle, raw)
+    assert int(b.lcp.max()) >= case["seg_len"] - 1 - case.get("n_run", 0) * 0 - (1 if case.get("mutate") else 0) * case["seg_len"]
+    assert b.stats.num_levels < 60
+    if case.get("n_run"):
+        assert_matches_oracle(ctx, oracle, raw, allow_ambiguity=True)
+
+
 def test_protein_alphabet(ctx, oracle):
     d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "uniprot.fa")
     assert_matches_oracle(ctx, oracle, np.frombuffer(d.seq, dtype=np.uint8), is_dna=False)
