@@ -68,11 +68,11 @@ typedef struct sufr_hip_stats {
     uint64_t deep_records;      /* records processed by deeper levels (all levels) */
     uint32_t top_lo, top_hi;    /* prefix-bucket range of this shard [lo, hi) */
     uint32_t partition_workgroups; /* grid of the radix-partition kernel */
-    uint32_t partition_variant; /* 3 = k_msd_scatter_text (bit-packed stream, alphabets of <= 15 symbols), 0 = k_scatter_text (text staging) */
+    uint32_t partition_variant; /* 3 = k_msd_part_text (bit-packed stream, alphabets of <= 15 symbols), 0 = k_scatter_text (text staging) */
     float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
     float ms_normalize;         /* k_normalize_pack_dna / k_normalize_bytehist */
     float ms_hist_text;         /* level-1 histogram over the text (k_msd_hist_text / k_hist_text) + cursor setup */
-    float ms_partition;         /* k_msd_scatter_text / k_scatter_text: THE radix-partition kernel (one launch) */
+    float ms_partition;         /* k_msd_part_text / k_scatter_text: THE radix-partition kernel (one launch) */
     float ms_passes;            /* further MSD levels + leaf sorts */
     float ms_finish;            /* k_finish of the top level */
     float ms_deep;              /* all deeper levels */

@@ -54,7 +54,8 @@ int usage(FILE* f)
             "  -i, --ignore-softmask             Ignore suffixes in soft-mask/lowercase regions\n"
             "  -D, --sequence-delimiter <DELIM>  Character to separate sequences [default: %%]\n"
             "  -s, --seed-mask <MASK>            Spaced seeds mask\n"
-            "  -r, --random-seed <RANDSEED>      Random seed [default: 42]\n");
+            "  -r, --random-seed <RANDSEED>      Random seed [default: 42]\n\n"
+            "Texts of 2^32 - 2^24 bytes and more are refused (64-bit device indices are not built yet).\n");
     return f == stderr ? 2 : 0;
 }
 

@@ -4,12 +4,15 @@
 //   * text normalisation            (143-160)  -> k_normalize_pack_dna / k_normalize_bytehist (+ run-end
 //                                                 tables, bit-packed code stream)
 //   * eligibility + upper_bound/is_less/find_lcp bucketing (346-394, 442-462)
-//                                              -> k_presence_hist_packed | k_digit_presence + k_hist_text,
-//                                                 then k_scatter_text / _sparse / _accum (radix partition
-//                                                 on packed k-char prefix keys, LDS staged)
-//   * merge_sort / merge            (601-767)  -> k_hist_pairs / k_scatter_pairs (further LSD passes)
-//                                                 + k_finish (wave-level tie refinement, exact LCP)
-//   * boundary LCP of write()       (886-906)  -> LCP at every group boundary comes from the key xor
+//                                              -> MSD partition levels on packed k-character prefix keys
+//                                                 (sufr_msd.inc: k_msd_part_text, k_msd_scatter; alphabets without
+//                                                 a packed stream: k_hist_text + k_scatter_text here)
+//   * merge_sort / merge            (601-767)  -> k_leaf_sort (sufr_msd.inc: in-LDS sort of a bucket, SA, LCP from
+//                                                 the key xor) + the tie / re-keying levels here (k_gather_keys,
+//                                                 k_hist_pairs / k_scatter_pairs, k_finish: wave-level tie
+//                                                 refinement, exact LCP) + prefix doubling (sufr_dbl.inc)
+//   * boundary LCP of write()       (886-906)  -> LCP at every group / window / shard boundary (key xor,
+//                                                 k_fix_window_lcp, k_lcp_pair)
 //
 // Integer / byte work, HBM-bound: no MFMA.  64-wide wavefronts are hard-coded.
 //
@@ -1406,8 +1409,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          uint32_t ncross)
 {
 #ifdef SUFR_HIP_PROBES
-    const uint32_t popts = ncross >> 30;            // timing probes: 1 = no pair walk, 2 = no walk keys
-    ncross &= 0x3fffffffu;
+    const uint32_t popts = ncross >> 29;            // timing probes: 1 = no pair walk, 2 = no walk keys, 4 = count the walks
+    ncross &= 0x1fffffffu;
 #else
     constexpr uint32_t popts = 0;
 #endif
@@ -1587,8 +1590,10 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
                     sg[slot] = 0u;
                     sg[slot + 1] = dnew + (uint32_t)k;
 #ifdef SUFR_HIP_PROBES
-                    atomicAdd(&g_walk_stats[0], 1ull); atomicAdd(&g_walk_stats[1], (unsigned long long)k);
-                    atomicMax(&g_walk_stats[2], (unsigned long long)k);
+                    if (popts & 4u) {
+                        atomicAdd(&g_walk_stats[0], 1ull); atomicAdd(&g_walk_stats[1], (unsigned long long)k);
+                        atomicMax(&g_walk_stats[2], (unsigned long long)k);
+                    }
 #endif
                 };
                 if (ph0) walk((uint32_t)ln, i0, dd0 + advance(k0));

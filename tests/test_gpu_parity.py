@@ -267,7 +267,7 @@ def test_sparse_partition_kernel_both_flush_modes(ctx, oracle):
     raw = np.concatenate(parts + [np.frombuffer(b"$", dtype=np.uint8)])
     b = assert_matches_oracle(ctx, oracle, raw)
     assert b.num_suffixes <= 0.55 * raw.size
-    assert b.stats.partition_variant == 3          # k_msd_scatter_text (bit-packed stream)
+    assert b.stats.partition_variant == 3          # k_msd_part_text (bit-packed stream)
 
 
 def test_empty_text(ctx):
