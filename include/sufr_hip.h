@@ -94,6 +94,10 @@ void sufr_hip_destroy(sufr_hip_ctx *ctx);
 const char *sufr_hip_last_error(const sufr_hip_ctx *ctx);
 /* optional: run the build on a caller-owned hipStream_t (e.g. torch's current stream) */
 int  sufr_hip_set_stream(sufr_hip_ctx *ctx, void *hip_stream);
+/* Waits for everything enqueued on the context's stream.  The context's own stream is non-blocking: work the caller
+ * queued on another stream (the producer of a device text, the consumer of device results) is NOT ordered against it;
+ * callers synchronise their producer before a call and use this after the calls that only enqueue. */
+int  sufr_hip_synchronize(sufr_hip_ctx *ctx);
 
 /* ---- text normalisation: sufr_builder.rs:144-160 (host helper; the GPU build can also do it) --- */
 int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_softmask);

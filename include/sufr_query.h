@@ -1,0 +1,90 @@
+/*
+ * sufr_query.h -- reading a version-6 .sufr file and searching it (host code; part of libsufr_hip.so).
+ *
+ * What each entry point replaces in the reference (TravisWheelerLab/sufr):
+ *   sufr_file_open        SufrFile::<T>::read                 libsufr/src/sufr_file.rs:145-275 (T chosen like
+ *                                                             SuffixArray::read, suffix_array.rs: u32 iff text_len < u32::MAX)
+ *   sufr_file_search      SufrSearch::search + compare        libsufr/src/sufr_search.rs:104-350, util.rs:19-37
+ *   sufr_file_metadata    SufrFile::metadata                  sufr_file.rs:484-507
+ *   accessors             FileAccess<T>::get / get_range      file_access.rs
+ * The commands built on them (count / locate / extract / list / summarize, sufr/src/lib.rs:292-646) live in the
+ * `sufr` binary (sufr_amd/csrc/sufr_cli.cpp) with the reference's output formats.
+ *
+ * The file is mapped read-only; nothing is copied.  max_query_len at query time: the reference searches a subsample
+ * of the suffix array (first suffix of every distinct L-prefix, sufr_file.rs:440-460, cached under ~/.sufr) and maps
+ * the hit back through ranks; here the whole array is searched with the same truncated comparison, which gives the
+ * same rank range for every case the reference's tests cover and the range of ALL matching suffixes where the
+ * reference's `rank[end] + 1` (sufr_search.rs:134) cuts the last group short.
+ */
+#ifndef SUFR_QUERY_H
+#define SUFR_QUERY_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sufr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sufr_file sufr_file;
+
+typedef struct sufr_file_meta {
+    uint8_t  version, is_dna, allow_ambiguity, ignore_softmask;
+    int      index_width;          /* 4 or 8: sizeof T */
+    uint64_t text_len, text_pos, suffix_array_pos, lcp_pos, len_suffixes;
+    uint64_t max_query_len;        /* of the build (0 when the file was built with a seed mask) */
+    uint64_t num_sequences;
+    uint64_t seed_mask_len;        /* 0: none */
+    uint64_t file_size;
+    int64_t  modified;             /* seconds since the epoch */
+} sufr_file_meta;
+
+int  sufr_file_open(const char *path, sufr_file **out, char *err, size_t errlen);
+void sufr_file_close(sufr_file *f);
+int  sufr_file_metadata(const sufr_file *f, sufr_file_meta *meta);
+const uint8_t *sufr_file_text(const sufr_file *f);                 /* text_len bytes */
+const uint8_t *sufr_file_seed_mask(const sufr_file *f);            /* seed_mask_len bytes of 0 / 1, or NULL */
+const void *sufr_file_suffix_array(const sufr_file *f);            /* len_suffixes entries of index_width bytes */
+const void *sufr_file_lcp_array(const sufr_file *f);
+uint64_t sufr_file_suffix(const sufr_file *f, uint64_t rank);      /* SA[rank] */
+uint64_t sufr_file_lcp(const sufr_file *f, uint64_t rank);         /* LCP[rank] */
+uint64_t sufr_file_sequence_start(const sufr_file *f, uint64_t i);
+const char *sufr_file_sequence_name(const sufr_file *f, uint64_t i);
+/* index of the sequence that holds text position `pos`: partition_point(start <= pos) - 1 (sufr_file.rs:1149) */
+uint64_t sufr_file_sequence_of(const sufr_file *f, uint64_t pos);
+
+/* One query.  Returns 1 and the half-open rank range [*rank_lo, *rank_hi) when the query occurs, 0 when it does not.
+ * has_max_query_len / max_query_len: the -m option of count / locate / extract. */
+int sufr_file_search(const sufr_file *f, const uint8_t *query, size_t query_len, int has_max_query_len,
+                     uint64_t max_query_len, uint64_t *rank_lo, uint64_t *rank_hi);
+
+/* ---- the same search for a batch of queries, on the GPU ---------------------------------------------------------
+ * Replaces the rayon loop of SuffixArray::count / locate (libsufr/src/suffix_array.rs:181-236, 340-366;
+ * sufr_file.rs:760-800): text and suffix array are resident in HBM, one launch answers the batch, one lane per
+ * query.  32-bit suffix arrays only (text_len < 2^32 - 1), like the device builder.
+ *
+ * sufr_hip_index_load   copies text + SA (+ seed mask) of an open file to the context's device.
+ * sufr_hip_index_wrap   wraps arrays that are already on the device -- e.g. the normalized text handed to
+ *                       sufr_hip_sort_device_u32 and the SA it produced: build, then query, without leaving HBM.
+ *                       The caller keeps ownership of d_text / d_sa.  seed_mask: the "1101"-style string or NULL.
+ * Queries are the concatenated query bytes plus num_queries + 1 offsets (query i = bytes [offsets[i], offsets[i+1])).
+ * rank_lo / rank_hi receive the half-open rank range per query, lo == hi == 0 when the query does not occur.
+ * _batch takes host buffers and returns when the answers are in rank_lo / rank_hi; _batch_device takes device buffers
+ * and only enqueues on the context's stream. */
+typedef struct sufr_hip_index sufr_hip_index;
+int  sufr_hip_index_load(sufr_hip_ctx *ctx, const sufr_file *f, sufr_hip_index **out);
+int  sufr_hip_index_wrap(sufr_hip_ctx *ctx, const void *d_text, uint64_t text_len, const void *d_sa, uint64_t num_suffixes,
+                         uint64_t built_max_query_len, const char *seed_mask, sufr_hip_index **out);
+void sufr_hip_index_free(sufr_hip_index *ix);
+int  sufr_hip_search_batch(sufr_hip_ctx *ctx, const sufr_hip_index *ix, const uint8_t *queries, const uint64_t *offsets,
+                           uint64_t num_queries, int has_max_query_len, uint64_t max_query_len, uint64_t *rank_lo,
+                           uint64_t *rank_hi);
+int  sufr_hip_search_batch_device(sufr_hip_ctx *ctx, const sufr_hip_index *ix, const void *d_queries, const void *d_offsets,
+                                  uint64_t num_queries, int has_max_query_len, uint64_t max_query_len, void *d_rank_lo,
+                                  void *d_rank_hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUFR_QUERY_H */

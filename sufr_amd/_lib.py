@@ -64,12 +64,30 @@ FLAG_DNA, FLAG_ALLOW_AMBIGUITY, FLAG_IGNORE_SOFTMASK, FLAG_RAW_TEXT = 1, 2, 4, 8
 # every symbol include/sufr_hip.h declares
 EXPORTS = [
     "sufr_hip_abi_version", "sufr_hip_device_count", "sufr_hip_create", "sufr_hip_destroy",
-    "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
+    "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_synchronize", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
     "sufr_hip_sort_device_u64", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
     "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file", "sufr_hip_create_from_sequence",
     "sufr_hip_shard_build", "sufr_write_frame", "sufr_hip_shard_write", "sufr_hip_create_from_sequence_multi",
     "sufr_hip_create_file_multi",
 ]
+# every symbol include/sufr_query.h declares
+QUERY_EXPORTS = [
+    "sufr_file_open", "sufr_file_close", "sufr_file_metadata", "sufr_file_text", "sufr_file_seed_mask",
+    "sufr_file_suffix_array", "sufr_file_lcp_array", "sufr_file_suffix", "sufr_file_lcp", "sufr_file_sequence_start",
+    "sufr_file_sequence_name", "sufr_file_sequence_of", "sufr_file_search",
+    "sufr_hip_index_load", "sufr_hip_index_wrap", "sufr_hip_index_free", "sufr_hip_search_batch",
+    "sufr_hip_search_batch_device",
+]
+
+
+class FileMeta(C.Structure):
+    """sufr_file_meta"""
+    _fields_ = [("version", C.c_uint8), ("is_dna", C.c_uint8), ("allow_ambiguity", C.c_uint8),
+                ("ignore_softmask", C.c_uint8), ("index_width", C.c_int),
+                ("text_len", C.c_uint64), ("text_pos", C.c_uint64), ("suffix_array_pos", C.c_uint64),
+                ("lcp_pos", C.c_uint64), ("len_suffixes", C.c_uint64), ("max_query_len", C.c_uint64),
+                ("num_sequences", C.c_uint64), ("seed_mask_len", C.c_uint64), ("file_size", C.c_uint64),
+                ("modified", C.c_int64)]
 
 _lib = None
 
@@ -99,6 +117,7 @@ def lib() -> C.CDLL:
     L.sufr_hip_destroy.argtypes = [vp]; L.sufr_hip_destroy.restype = None
     L.sufr_hip_last_error.argtypes = [vp]; L.sufr_hip_last_error.restype = cp
     L.sufr_hip_set_stream.argtypes = [vp, vp]; L.sufr_hip_set_stream.restype = C.c_int
+    L.sufr_hip_synchronize.argtypes = [vp]; L.sufr_hip_synchronize.restype = C.c_int
     L.sufr_hip_normalize.argtypes = [vp, vp, u64, C.c_int]; L.sufr_hip_normalize.restype = C.c_int
     dev_sig = [vp, vp, u64, u32, u64, cp, u64, u64, u32, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(Stats)]
     L.sufr_hip_sort_device_u32.argtypes = dev_sig; L.sufr_hip_sort_device_u32.restype = C.c_int
@@ -132,6 +151,23 @@ def lib() -> C.CDLL:
     L.sufr_hip_create_file_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(CreateArgs), cp, C.c_size_t,
                                              C.POINTER(Stats)]
     L.sufr_hip_create_file_multi.restype = C.c_int
+    # include/sufr_query.h
+    L.sufr_file_open.argtypes = [cp, C.POINTER(vp), cp, C.c_size_t]; L.sufr_file_open.restype = C.c_int
+    L.sufr_file_close.argtypes = [vp]; L.sufr_file_close.restype = None
+    L.sufr_file_metadata.argtypes = [vp, C.POINTER(FileMeta)]; L.sufr_file_metadata.restype = C.c_int
+    for name in ("sufr_file_text", "sufr_file_seed_mask", "sufr_file_suffix_array", "sufr_file_lcp_array"):
+        getattr(L, name).argtypes = [vp]; getattr(L, name).restype = vp
+    for name in ("sufr_file_suffix", "sufr_file_lcp", "sufr_file_sequence_start", "sufr_file_sequence_of"):
+        getattr(L, name).argtypes = [vp, u64]; getattr(L, name).restype = u64
+    L.sufr_file_sequence_name.argtypes = [vp, u64]; L.sufr_file_sequence_name.restype = cp
+    L.sufr_file_search.argtypes = [vp, cp, C.c_size_t, C.c_int, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.sufr_file_search.restype = C.c_int
+    L.sufr_hip_index_load.argtypes = [vp, vp, C.POINTER(vp)]; L.sufr_hip_index_load.restype = C.c_int
+    L.sufr_hip_index_wrap.argtypes = [vp, vp, u64, vp, u64, u64, cp, C.POINTER(vp)]; L.sufr_hip_index_wrap.restype = C.c_int
+    L.sufr_hip_index_free.argtypes = [vp]; L.sufr_hip_index_free.restype = None
+    L.sufr_hip_search_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]; L.sufr_hip_search_batch.restype = C.c_int
+    L.sufr_hip_search_batch_device.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]
+    L.sufr_hip_search_batch_device.restype = C.c_int
     _lib = L
     return L
 
@@ -160,6 +196,9 @@ class Context:
     def check(self, rc: int):
         if rc != 0:
             raise SufrHipError(rc, lib().sufr_hip_last_error(self._h).decode())
+
+    def synchronize(self):
+        self.check(lib().sufr_hip_synchronize(self._h))
 
     @property
     def handle(self):

@@ -2,8 +2,9 @@
 //
 // Command-line contract of the reference for this path: sufr/src/lib.rs:29-46 (global -t/--threads,
 // -l/--log, --log-file), 83-125 (CreateArgs, alias `cr`), sufr/src/main.rs:8-40 (errors are printed as
-// "Error: <msg>" and exit code 1).  Query sub-commands (count/extract/list/locate/summarize) are not
-// part of the construction path and are not provided here.
+// "Error: <msg>" and exit code 1).  The query sub-commands (count / locate / extract / list / summarize,
+// sufr/src/lib.rs:129-271 for their arguments, 292-646 for their output) read the file through
+// include/sufr_query.h; their output is the reference's, character for character.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +17,12 @@
 #include <vector>
 
 #include "../../include/sufr_hip.h"
+#include "../../include/sufr_query.h"
+
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+#include <time.h>
 
 namespace {
 
@@ -37,7 +44,14 @@ std::string with_commas(uint64_t v)
 int usage(FILE* f)
 {
     fprintf(f,
-            "Usage: sufr [OPTIONS] create|cr [OPTIONS] <INPUT>\n\n"
+            "Usage: sufr [OPTIONS] <COMMAND> ...\n\n"
+            "Commands:\n"
+            "  create|cr    <INPUT>                 Create sufr file (on the GPU)\n"
+            "  count|co     <SUFR> <QUERY>...       Count occurrences of sequences [-m LEN] [-o OUT] [-l] [-v]\n"
+            "  locate|lo    <SUFR> <QUERY>...       Locate sequences [-a] [-m LEN] [-o OUT] [-l] [-v]\n"
+            "  extract|ex   <SUFR> <QUERY>...       Extract sequences [-p PREFIX_LEN] [-s SUFFIX_LEN] [-m LEN] [-o OUT] [-l] [-v]\n"
+            "  list|ls      <FILE> [RANK]...        List the suffix array [-r] [-s] [-p] [--len LEN] [-n NUM] [-o OUT] [-v]\n"
+            "  summarize|su <SUFR>                  Summarize sufr file\n\n"
             "Global options:\n"
             "  -t, --threads <THREADS>   Accepted for compatibility (the build runs on the GPU)\n"
             "  -l, --log <LOG>           Log level [possible values: info, debug]\n"
@@ -57,6 +71,321 @@ int usage(FILE* f)
             "  -r, --random-seed <RANDSEED>      Random seed [default: 42]\n\n"
             "Texts of 2^32 - 2^24 bytes and more are refused (64-bit device indices are not built yet).\n");
     return f == stderr ? 2 : 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// query sub-commands (sufr/src/lib.rs:292-646)
+// ---------------------------------------------------------------------------------------------------------------
+struct QueryArgs {
+    std::string file, output;
+    std::vector<std::string> positional;        // queries / ranks
+    bool has_mql = false; uint64_t mql = 0;
+    bool abs = false;
+    bool has_prefix = false, has_suffix = false; uint64_t prefix_len = 0, suffix_len = 0;
+    bool show_rank = false, show_suffix = false, show_lcp = false;
+    bool has_len = false, has_number = false; uint64_t len = 0, number = 0;
+};
+
+// parse_locate_queries (lib.rs:449-466): an argument that names an existing file is read as whitespace-separated queries
+std::vector<std::string> expand_queries(const std::vector<std::string>& args)
+{
+    std::vector<std::string> out;
+    for (const std::string& a : args) {
+        struct stat sb;
+        if (stat(a.c_str(), &sb) == 0) {
+            std::ifstream in(a);
+            std::string w;
+            while (in >> w) out.push_back(w);
+        } else out.push_back(a);
+    }
+    return out;
+}
+
+struct OutFile {
+    FILE* f = stdout;
+    bool open(const std::string& name)
+    {
+        if (name.empty()) return true;
+        f = fopen(name.c_str(), "w");
+        return f != nullptr;
+    }
+    ~OutFile() { if (f && f != stdout) fclose(f); }
+};
+
+sufr_file* open_or_die(const std::string& path)
+{
+    char err[512] = {0};
+    sufr_file* f = nullptr;
+    if (sufr_file_open(path.c_str(), &f, err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); exit(1); }
+    return f;
+}
+
+int cmd_count(const QueryArgs& a)
+{
+    sufr_file* f = open_or_die(a.file);
+    OutFile out;
+    if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
+    for (const std::string& q : expand_queries(a.positional)) {
+        uint64_t lo = 0, hi = 0;
+        const int hit = sufr_file_search(f, (const uint8_t*)q.data(), q.size(), a.has_mql, a.mql, &lo, &hi);
+        fprintf(out.f, "%s %llu\n", q.c_str(), (unsigned long long)(hit ? hi - lo : 0));
+    }
+    sufr_file_close(f);
+    return 0;
+}
+
+int cmd_locate(const QueryArgs& a)
+{
+    sufr_file* f = open_or_die(a.file);
+    OutFile out;
+    if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
+    for (const std::string& q : expand_queries(a.positional)) {
+        uint64_t lo = 0, hi = 0;
+        if (!sufr_file_search(f, (const uint8_t*)q.data(), q.size(), a.has_mql, a.mql, &lo, &hi)) {
+            fprintf(stderr, "%s not found\n", q.c_str());
+            continue;
+        }
+        if (a.abs) {
+            std::string line = q;
+            for (uint64_t r = lo; r < hi; r++) line += " " + std::to_string(sufr_file_suffix(f, r));
+            fprintf(out.f, "%s\n", line.c_str());
+            continue;
+        }
+        // by sequence name, then position inside the sequence (lib.rs:513-518)
+        struct Pos { std::string name; uint64_t at; };
+        std::vector<Pos> ps;
+        for (uint64_t r = lo; r < hi; r++) {
+            const uint64_t sfx = sufr_file_suffix(f, r);
+            const uint64_t i = sufr_file_sequence_of(f, sfx);
+            ps.push_back({sufr_file_sequence_name(f, i), sfx - sufr_file_sequence_start(f, i)});
+        }
+        std::stable_sort(ps.begin(), ps.end(), [](const Pos& x, const Pos& y) { return x.name != y.name ? x.name < y.name : x.at < y.at; });
+        fprintf(out.f, "%s\n", q.c_str());
+        std::string prev, buf;
+        for (const Pos& p : ps) {
+            if (p.name != prev) {
+                if (!buf.empty()) fprintf(out.f, "%s %s\n", prev.c_str(), buf.c_str());
+                prev = p.name; buf.clear();
+            }
+            if (!buf.empty()) buf += ",";
+            buf += std::to_string(p.at);
+        }
+        if (!buf.empty()) fprintf(out.f, "%s %s\n", prev.c_str(), buf.c_str());
+        fprintf(out.f, "//\n");
+    }
+    sufr_file_close(f);
+    return 0;
+}
+
+int cmd_extract(const QueryArgs& a)
+{
+    sufr_file* f = open_or_die(a.file);
+    OutFile out;
+    if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
+    sufr_file_meta m; sufr_file_metadata(f, &m);
+    const uint8_t* text = sufr_file_text(f);
+    for (const std::string& q : expand_queries(a.positional)) {
+        uint64_t lo = 0, hi = 0;
+        if (!sufr_file_search(f, (const uint8_t*)q.data(), q.size(), a.has_mql, a.mql, &lo, &hi)) {
+            fprintf(stderr, "%s not found\n", q.c_str());
+            continue;
+        }
+        for (uint64_t r = lo; r < hi; r++) {          // SufrFile::extract (sufr_file.rs:898-960)
+            const uint64_t sfx = sufr_file_suffix(f, r);
+            const uint64_t i = sufr_file_sequence_of(f, sfx);
+            const uint64_t seq_start = sufr_file_sequence_start(f, i);
+            const uint64_t seq_end = i + 1 == m.num_sequences ? m.text_len : sufr_file_sequence_start(f, i + 1);
+            const uint64_t rel = sfx - seq_start;
+            const uint64_t cstart = rel > (a.has_prefix ? a.prefix_len : 0) ? rel - (a.has_prefix ? a.prefix_len : 0) : 0;
+            uint64_t cend = a.has_suffix ? rel + a.suffix_len : seq_end;
+            if (cend > seq_end) cend = seq_end;
+            // string_at(sequence_start + range.start, Some(range.end - range.start)) (sufr_file.rs:399-411)
+            const uint64_t from = seq_start + cstart;
+            uint64_t to = from + (cend > cstart ? cend - cstart : 0);
+            if (to > m.text_len) to = m.text_len;
+            fprintf(out.f, ">%s:%llu-%llu %s %llu\n", sufr_file_sequence_name(f, i), (unsigned long long)cstart,
+                    (unsigned long long)cend, q.c_str(), (unsigned long long)(rel - cstart));
+            fwrite(text + from, 1, (size_t)(to > from ? to - from : 0), out.f);
+            fputc('\n', out.f);
+        }
+    }
+    sufr_file_close(f);
+    return 0;
+}
+
+// parse_index / parse_pos (lib.rs:556-590): "3", "1,5", "2-4" (inclusive)
+bool parse_ranks(const std::string& arg, std::vector<uint64_t>& out, std::string& err)
+{
+    size_t p = 0;
+    while (p <= arg.size()) {
+        size_t q = arg.find(',', p);
+        if (q == std::string::npos) q = arg.size();
+        const std::string val = arg.substr(p, q - p);
+        auto is_num = [](const std::string& s) { return !s.empty() && s.find_first_not_of("0123456789") == std::string::npos; };
+        const size_t dash = val.find('-');
+        if (is_num(val)) out.push_back(strtoull(val.c_str(), nullptr, 10));
+        else if (dash != std::string::npos && is_num(val.substr(0, dash)) && is_num(val.substr(dash + 1))) {
+            const uint64_t n1 = strtoull(val.substr(0, dash).c_str(), nullptr, 10), n2 = strtoull(val.substr(dash + 1).c_str(), nullptr, 10);
+            if (n1 >= n2) {
+                err = "First number in range (" + std::to_string(n1) + ") must be lower than second number (" + std::to_string(n2) + ")";
+                return false;
+            }
+            for (uint64_t v = n1; v <= n2; v++) out.push_back(v);
+        } else { err = "illegal list value: \"" + val + "\""; return false; }
+        p = q + 1;
+    }
+    return true;
+}
+
+int cmd_list(const QueryArgs& a)
+{
+    sufr_file* f = open_or_die(a.file);
+    OutFile out;
+    if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
+    std::vector<uint64_t> ranks;
+    for (const std::string& r : a.positional) {
+        std::string err;
+        if (!parse_ranks(r, ranks, err)) { fprintf(stderr, "Error: %s\n", err.c_str()); sufr_file_close(f); return 1; }
+    }
+    sufr_file_meta m; sufr_file_metadata(f, &m);
+    const uint8_t* text = sufr_file_text(f);
+    const int width = (int)std::to_string(m.text_len).size();
+    const uint64_t suffix_len = a.has_len ? a.len : m.text_len;
+    auto print = [&](uint64_t rank) {                      // SufrFile::list (sufr_file.rs:1013-1077)
+        const uint64_t sfx = sufr_file_suffix(f, rank);
+        const uint64_t end = sfx + suffix_len > m.text_len ? m.text_len : sfx + suffix_len;
+        if (a.show_rank) fprintf(out.f, "%*llu ", width, (unsigned long long)rank);
+        if (a.show_suffix) fprintf(out.f, "%*llu ", width, (unsigned long long)sfx);
+        if (a.show_lcp) fprintf(out.f, "%*llu ", width, (unsigned long long)sufr_file_lcp(f, rank));
+        fwrite(text + sfx, 1, (size_t)(end - sfx), out.f);
+        fputc('\n', out.f);
+    };
+    if (ranks.empty()) {
+        const uint64_t number = a.has_number ? a.number : 0;
+        for (uint64_t r = 0; r < m.len_suffixes; r++) {
+            print(r);
+            if (number > 0 && r == number - 1) break;
+        }
+    } else {
+        for (uint64_t r : ranks) {
+            if (r < m.len_suffixes) print(r);
+            else fprintf(stderr, "Invalid rank: %llu\n", (unsigned long long)r);
+        }
+    }
+    sufr_file_close(f);
+    return 0;
+}
+
+// textwrap::wrap(s, width): greedy, breaks at spaces
+std::vector<std::string> wrap_text(const std::string& s, size_t width)
+{
+    std::vector<std::string> lines;
+    std::istringstream in(s);
+    std::string w, cur;
+    while (in >> w) {
+        if (!cur.empty() && cur.size() + 1 + w.size() > width) { lines.push_back(cur); cur.clear(); }
+        cur += (cur.empty() ? "" : " ") + w;
+    }
+    lines.push_back(cur);
+    return lines;
+}
+
+int cmd_summarize(const QueryArgs& a)
+{
+    sufr_file* f = open_or_die(a.file);
+    sufr_file_meta m; sufr_file_metadata(f, &m);
+    std::vector<std::pair<std::string, std::vector<std::string>>> rows;     // name, value lines
+    auto row = [&](const std::string& k, const std::string& v) { rows.push_back({k, {v}}); };
+    row("Filename", a.file);
+    {
+        char buf[64];
+        time_t t = (time_t)m.modified;
+        struct tm tmv;
+        localtime_r(&t, &tmv);
+        strftime(buf, sizeof buf, "%Y-%m-%d %H:%M", &tmv);
+        row("Modified", buf);
+    }
+    row("File Size", with_commas(m.file_size) + " bytes");
+    row("File Version", std::to_string(m.version));
+    row("DNA", m.is_dna ? "true" : "false");
+    row("Allow Ambiguity", m.allow_ambiguity ? "true" : "false");
+    row("Ignore Softmask", m.ignore_softmask ? "true" : "false");
+    row("Text Length", with_commas(m.text_len));
+    row("Len Suffixes", with_commas(m.len_suffixes));
+    if (m.seed_mask_len) {
+        std::string mask;
+        const uint8_t* mb = sufr_file_seed_mask(f);
+        for (uint64_t i = 0; i < m.seed_mask_len; i++) mask += mb[i] ? '1' : '0';
+        row("Seed mask", mask);
+    } else row("Max query len", with_commas(m.max_query_len));
+    row("Num sequences", with_commas(m.num_sequences));
+    std::string starts, names;
+    for (uint64_t i = 0; i < m.num_sequences; i++) {
+        starts += (i ? ", " : "") + std::to_string(sufr_file_sequence_start(f, i));
+        names += std::string(i ? ", " : "") + sufr_file_sequence_name(f, i);
+    }
+    rows.push_back({"Sequence starts", wrap_text(starts, 40)});
+    rows.push_back({"Sequence names", wrap_text(names, 40)});
+    // tabled's default style: +---+---+ between rows, cells padded by one blank
+    size_t w0 = 0, w1 = 0;
+    for (auto& r : rows) { w0 = std::max(w0, r.first.size()); for (auto& l : r.second) w1 = std::max(w1, l.size()); }
+    const std::string rule = "+" + std::string(w0 + 2, '-') + "+" + std::string(w1 + 2, '-') + "+";
+    printf("%s\n", rule.c_str());
+    for (auto& r : rows) {
+        for (size_t i = 0; i < r.second.size(); i++)
+            printf("| %-*s | %-*s |\n", (int)w0, i == 0 ? r.first.c_str() : "", (int)w1, r.second[i].c_str());
+        printf("%s\n", rule.c_str());
+    }
+    sufr_file_close(f);
+    return 0;
+}
+
+// arguments of the query sub-commands (clap definitions of lib.rs:129-271)
+int run_query(const std::string& cmd, int argc, char** argv, int first)
+{
+    QueryArgs a;
+    std::vector<std::string> pos;
+    auto need = [&](int& i, const char* opt) -> const char* {
+        if (i + 1 >= argc) { fprintf(stderr, "error: a value is required for '%s'\n", opt); exit(2); }
+        return argv[++i];
+    };
+    const bool is_list = cmd == "list", is_extract = cmd == "extract", is_locate = cmd == "locate", is_sum = cmd == "summarize";
+    for (int i = first; i < argc; i++) {
+        const std::string s = argv[i];
+        if (s == "-h" || s == "--help") { usage(stdout); return 0; }
+        else if (!is_list && !is_sum && (s == "-m" || s == "--max-query-len")) { a.has_mql = true; a.mql = strtoull(need(i, "-m"), nullptr, 10); }
+        else if (!is_sum && (s == "-o" || s == "--output")) a.output = need(i, "-o");
+        else if (!is_list && !is_sum && (s == "-l" || s == "--low-memory")) {}            // access mode only: the file is mapped
+        else if (!is_sum && (s == "-v" || s == "--very-low-memory")) {}
+        else if (is_locate && (s == "-a" || s == "--abs")) a.abs = true;
+        else if (is_extract && (s == "-p" || s == "--prefix-len")) { a.has_prefix = true; a.prefix_len = strtoull(need(i, "-p"), nullptr, 10); }
+        else if (is_extract && (s == "-s" || s == "--suffix-len")) { a.has_suffix = true; a.suffix_len = strtoull(need(i, "-s"), nullptr, 10); }
+        else if (is_list && (s == "-r" || s == "--show-rank")) a.show_rank = true;
+        else if (is_list && (s == "-s" || s == "--show-suffix")) a.show_suffix = true;
+        else if (is_list && (s == "-p" || s == "--show-lcp")) a.show_lcp = true;
+        else if (is_list && s == "--len") { a.has_len = true; a.len = strtoull(need(i, "--len"), nullptr, 10); }
+        else if (is_list && (s == "-n" || s == "--number")) { a.has_number = true; a.number = strtoull(need(i, "-n"), nullptr, 10); }
+        else if (is_list && s.size() > 2 && s[0] == '-' && s[1] != '-' && s.find_first_not_of("rspv", 1) == std::string::npos) {
+            for (size_t k = 1; k < s.size(); k++) {     // combined short flags: -rsp
+                if (s[k] == 'r') a.show_rank = true; else if (s[k] == 's') a.show_suffix = true; else if (s[k] == 'p') a.show_lcp = true;
+            }
+        }
+        else if (!s.empty() && s[0] == '-' && s.size() > 1) { fprintf(stderr, "error: unexpected argument '%s'\n", s.c_str()); return 2; }
+        else pos.push_back(s);
+    }
+    if (pos.empty()) { fprintf(stderr, "error: the following required arguments were not provided:\n  <%s>\n", is_list ? "FILE" : "SUFR"); return 2; }
+    a.file = pos[0];
+    a.positional.assign(pos.begin() + 1, pos.end());
+    if (!is_list && !is_sum && a.positional.empty()) {
+        fprintf(stderr, "error: the following required arguments were not provided:\n  <QUERY>...\n");
+        return 2;
+    }
+    if (cmd == "count") return cmd_count(a);
+    if (is_locate) return cmd_locate(a);
+    if (is_extract) return cmd_extract(a);
+    if (is_list) return cmd_list(a);
+    return cmd_summarize(a);
 }
 
 }  // namespace
@@ -103,7 +432,12 @@ int main(int argc, char** argv)
             }
         }
         else if (!have_cmd && (s == "create" || s == "cr")) have_cmd = true;
-        else if (!have_cmd) { fprintf(stderr, "error: unrecognized subcommand '%s' (this build provides `create`)\n", s.c_str()); return 2; }
+        else if (!have_cmd && (s == "count" || s == "co")) return run_query("count", argc, argv, i + 1);
+        else if (!have_cmd && (s == "locate" || s == "lo")) return run_query("locate", argc, argv, i + 1);
+        else if (!have_cmd && (s == "extract" || s == "ex")) return run_query("extract", argc, argv, i + 1);
+        else if (!have_cmd && (s == "list" || s == "ls")) return run_query("list", argc, argv, i + 1);
+        else if (!have_cmd && (s == "summarize" || s == "su")) return run_query("summarize", argc, argv, i + 1);
+        else if (!have_cmd) { fprintf(stderr, "error: unrecognized subcommand '%s'\n", s.c_str()); return 2; }
         else if (s == "-n" || s == "--num-partitions") a.num_partitions = strtoull(need(i, "-n"), nullptr, 10);
         else if (s == "-m" || s == "--max-query-len") { a.has_max_query_len = 1; a.max_query_len = strtoull(need(i, "-m"), nullptr, 10); }
         else if (s == "-o" || s == "--output") { output = need(i, "-o"); have_output = true; }

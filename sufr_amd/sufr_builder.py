@@ -108,6 +108,8 @@ class DeviceBuilder:
         u32 values (views of length num_suffixes)."""
         import torch
         assert d_text.is_cuda and d_text.dtype == torch.uint8 and d_text.is_contiguous()
+        # the context's stream is not ordered against torch's: whatever produced d_text must have finished
+        torch.cuda.current_stream(d_text.device).synchronize()
         n = d_text.numel()
         cap = n if out_sa is None else out_sa.numel()
         if out_sa is None:

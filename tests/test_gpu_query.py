@@ -1,0 +1,152 @@
+"""Batched search on the GPU (include/sufr_query.h, device section) against the host search of the same library and
+against properties of the answer that do not depend on either: every rank inside the range matches the query, the ranks
+on both sides do not."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import sufr_amd
+from sufr_amd import DeviceIndex, SufrFile, pack_queries
+from oracle_helper import GOLDEN
+from test_query import random_queries, witness_ranks
+
+pytestmark = pytest.mark.gpu
+EXP = GOLDEN / "expected"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sufr_amd.Context(0)
+    yield c
+    c.close()
+
+
+def host_ranges(f, queries, mql):
+    lo = np.zeros(len(queries), dtype=np.uint64)
+    hi = np.zeros(len(queries), dtype=np.uint64)
+    for i, q in enumerate(queries):
+        r = f.search(q, mql)
+        if r:
+            lo[i], hi[i] = r
+    return lo, hi
+
+
+@pytest.mark.parametrize("name", sorted(p.name for p in EXP.glob("*.sufr")))
+@pytest.mark.parametrize("mql", [None, 1, 3, 6])
+def test_device_search_equals_host_search_on_golden_files(ctx, name, mql):
+    f = SufrFile(EXP / name)
+    ix = DeviceIndex.load(ctx, f)
+    rng = np.random.default_rng(zlib.crc32(f"{name}{mql}".encode()))
+    max_len = len(f.seed_mask) if f.seed_mask else 16
+    queries = random_queries(rng, f, 3000, max_len)
+    lo, hi = ix.search(queries, mql)
+    wlo, whi = host_ranges(f, queries, mql)
+    assert np.array_equal(lo, wlo) and np.array_equal(hi, whi)
+    assert (hi > lo).sum() > 0
+    if f.text_len < 3000:                                   # and the scan of every rank, where that is cheap
+        for i in range(0, len(queries), 37):
+            want = witness_ranks(f, queries[i], mql)
+            assert (int(lo[i]), int(hi[i])) == ((want[0], want[-1] + 1) if want else (0, 0))
+    ix.close()
+
+
+def test_reference_cli_vectors_on_the_device(ctx):          # sufr/tests/cli.rs:339-360, 949-1060
+    f = SufrFile(EXP / "1.sufr")
+    assert [c.count for c in DeviceIndex.load(ctx, f).count(["AC", "X", "GT"])] == [2, 0, 2]
+    f = SufrFile(EXP / "uniprot-masked.sufr")
+    lo, hi = DeviceIndex.load(ctx, f).search(["RNEL"])
+    assert f.suffix_array[int(lo[0]):int(hi[0])].tolist() == [54791, 46515, 37970, 62005, 52278, 6386, 4124]
+    f = SufrFile(EXP / "long_dna_sequence.sufr")
+    lo, hi = DeviceIndex.load(ctx, f).search(["CATGTTGTCACG", "CCATGGGAC", "GGATGAAGAAAAGCA"], 6)
+    assert [sorted(f.suffix_array[int(a):int(b)].tolist()) for a, b in zip(lo, hi)] == \
+        [[2566, 13056, 20444], [3014], [1026, 2905, 13253, 13508, 14250, 14624, 20465]]
+
+
+def test_empty_batch_and_empty_query(ctx):
+    f = SufrFile(EXP / "1.sufr")
+    ix = DeviceIndex.load(ctx, f)
+    lo, hi = ix.search([])
+    assert lo.size == 0 and hi.size == 0
+    lo, hi = ix.search([b"", b"AC"])
+    assert (lo.tolist(), hi.tolist()) == ([0, 1], [9, 3])
+
+
+def check_range_properties(text, sa, qbytes, off, lo, hi, sample):
+    """text, sa: numpy; for the sampled queries: SA[lo], SA[hi-1] start with the query, SA[lo-1] and SA[hi] do not,
+    and when the query does not occur the text does not contain it (checked by bytes.find on a window is too slow at this
+    size: the miss side is covered by comparing with the host search)."""
+    n, s = text.size, sa.size
+    tb = text.tobytes()
+
+    def starts_with(pos, q):
+        return tb[pos:pos + len(q)] == q
+
+    for i in sample:
+        q = qbytes[int(off[i]):int(off[i + 1])].tobytes()
+        a, b = int(lo[i]), int(hi[i])
+        if b > a:
+            assert starts_with(int(sa[a]), q) and starts_with(int(sa[b - 1]), q)
+            assert a == 0 or not starts_with(int(sa[a - 1]), q)
+            assert b == s or not starts_with(int(sa[b]), q)
+            mid = (a + b) // 2
+            assert starts_with(int(sa[mid]), q)
+
+
+def test_build_then_query_without_leaving_the_device(ctx, tmp_path):
+    """20 Mb of DNA with planted repeats: built by the device builder, wrapped in place, 200 000 queries; the same file
+    written to disk and searched by the host code gives the same ranges."""
+    dev = "cuda"
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    n = 20_000_001
+    x = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n,), generator=g, device=dev)]
+    x[5_000_000:5_200_000] = x[1_000_000:1_200_000]
+    x[9_000_000:9_000_500] = ord("A")
+    x[-1] = ord("$")
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True)
+    ix = DeviceIndex.wrap(db.ctx, x, sa)
+    text = x.cpu().numpy()
+    sa_h = sa.cpu().numpy().view(np.uint32)
+    rng = np.random.default_rng(9)
+    nq = 200_000
+    lens = rng.integers(4, 41, nq)
+    at = rng.integers(0, n - 64, nq)
+    off = np.zeros(nq + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
+    qb = np.empty(int(off[-1]), dtype=np.uint8)
+    for i in range(nq):
+        qb[int(off[i]):int(off[i + 1])] = text[at[i]:at[i] + lens[i]]
+    flip = rng.integers(0, qb.size, nq // 3)                  # a third of the queries get one changed symbol
+    qb[flip] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, flip.size)]
+    lo, hi = ix.search_packed(qb, off)
+    found = hi > lo
+    assert 0.6 < found.mean() < 1.0
+    assert int((hi - lo).max()) > 400                           # the poly-A run
+    check_range_properties(text, sa_h, qb, off, lo, hi, rng.integers(0, nq, 20_000))
+    # device buffers in, device buffers out
+    dlo, dhi = ix.search_device(torch.from_numpy(qb).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev))
+    assert np.array_equal(dlo.cpu().numpy().astype(np.uint64), lo) and np.array_equal(dhi.cpu().numpy().astype(np.uint64), hi)
+    # the host search of the written file
+    path = tmp_path / "x.sufr"
+    lcp_h = lcp.cpu().numpy().view(np.uint32)
+    err = C.create_string_buffer(256)
+    starts = np.zeros(1, dtype=np.uint64)
+    names = (C.c_char_p * 1)(b"1")
+    rc = sufr_amd.lib().sufr_write_file(str(path).encode(), 1, 0, 0, text.ctypes.data, n, 4, sa_h.ctypes.data, lcp_h.ctypes.data,
+                                        sa_h.size, 0, 0, None, starts.ctypes.data, 1, names, err, len(err))
+    assert rc == 0, err.value
+    f = SufrFile(path)
+    sub = rng.integers(0, nq, 20_000)
+    for i in sub:
+        r = f.search(qb[int(off[i]):int(off[i + 1])].tobytes())
+        assert (int(lo[i]), int(hi[i])) == (r if r else (0, 0))
+    ix.close()
+    db.close()
+
+
+def test_index_of_another_width_or_device_is_refused(ctx):
+    x = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        DeviceIndex.wrap(ctx, x, torch.zeros(4, dtype=torch.int64, device="cuda"))
