@@ -98,6 +98,11 @@ int  sufr_hip_set_stream(sufr_hip_ctx *ctx, void *hip_stream);
  * queued on another stream (the producer of a device text, the consumer of device results) is NOT ordered against it;
  * callers synchronise their producer before a call and use this after the calls that only enqueue. */
 int  sufr_hip_synchronize(sufr_hip_ctx *ctx);
+/* Texts of 2^32 - 2^24 bytes and more (the u64 arm of SuffixArray::write, suffix_array.rs:460-470) are built in
+ * overlapping 32-bit windows that are merged by rank on the device (sufr_wide.inc).  window: positions per window,
+ * margin: comparison context after them; 0, 0 selects the defaults (as few windows as fit, 2^26).  A non-zero window
+ * also sends shorter texts of more than `window` bytes down the same path (memory-bound callers; the tests). */
+int  sufr_hip_set_window(sufr_hip_ctx *ctx, uint64_t window, uint64_t margin);
 
 /* ---- text normalisation: sufr_builder.rs:144-160 (host helper; the GPU build can also do it) --- */
 int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_softmask);

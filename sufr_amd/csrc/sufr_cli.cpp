@@ -68,8 +68,11 @@ int usage(FILE* f)
             "  -i, --ignore-softmask             Ignore suffixes in soft-mask/lowercase regions\n"
             "  -D, --sequence-delimiter <DELIM>  Character to separate sequences [default: %%]\n"
             "  -s, --seed-mask <MASK>            Spaced seeds mask\n"
-            "  -r, --random-seed <RANDSEED>      Random seed [default: 42]\n\n"
-            "Texts of 2^32 - 2^24 bytes and more are refused (64-bit device indices are not built yet).\n");
+            "  -r, --random-seed <RANDSEED>      Random seed [default: 42]\n"
+            "      --window <POSITIONS>          Build texts longer than this in overlapping windows merged on the device\n"
+            "                                    [default: one window below 2^32 - 2^24 bytes, as few as fit above]\n"
+            "      --margin <POSITIONS>          Comparison context after every window [default: 2^26]\n\n"
+            "Texts of 2^32 - 2^24 bytes and more are built in overlapping 32-bit windows merged on the device (one GPU).\n");
     return f == stderr ? 2 : 0;
 }
 
@@ -396,6 +399,7 @@ int main(int argc, char** argv)
     std::string log_file, input, output, seed_mask, delim = "%";
     int device = 0;
     std::vector<int> devices;
+    uint64_t window = 0, margin = 0;
     bool have_cmd = false, have_output = false, have_mask = false;
     sufr_create_args a;
     memset(&a, 0, sizeof a);
@@ -447,6 +451,8 @@ int main(int argc, char** argv)
         else if (s == "-D" || s == "--sequence-delimiter") delim = need(i, "-D");
         else if (s == "-s" || s == "--seed-mask") { seed_mask = need(i, "-s"); have_mask = true; }
         else if (s == "-r" || s == "--random-seed") a.random_seed = strtoull(need(i, "-r"), nullptr, 10);
+        else if (s == "--window") window = strtoull(need(i, "--window"), nullptr, 10);
+        else if (s == "--margin") margin = strtoull(need(i, "--margin"), nullptr, 10);
         else if (!s.empty() && s[0] == '-' && s.size() > 1) { fprintf(stderr, "error: unexpected argument '%s'\n", s.c_str()); return 2; }
         else if (input.empty()) input = s;
         else { fprintf(stderr, "error: unexpected argument '%s'\n", s.c_str()); return 2; }
@@ -500,6 +506,7 @@ int main(int argc, char** argv)
         for (size_t r = 0; r < devices.size(); r++) ids += (r ? "," : "") + std::to_string(devices[r]);
         log.info(std::string("Using HIP device") + (devices.size() > 1 ? "s " : " ") + ids);
     }
+    if (window || margin) for (auto* c : ctxs) sufr_hip_set_window(c, window, margin);
     char path[4096];
     std::vector<sufr_hip_stats> sts(devices.size());
     memset(sts.data(), 0, sts.size() * sizeof(sufr_hip_stats));

@@ -278,6 +278,7 @@ bool pwrite_all(int fd, const void* buf, size_t len, uint64_t off)
 }  // namespace
 
 extern "C" void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg);  // sufr_capi.inc
+extern "C" int sufr_hip_is_wide_(const sufr_hip_ctx* ctx, uint64_t n);
 extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t flags,
                                         uint64_t max_query_len, const char* seed_mask, uint32_t shard_index,
                                         uint32_t num_shards, uint64_t* num_suffixes, sufr_hip_stats* stats,
@@ -584,8 +585,8 @@ int sufr_hip_shard_build(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const 
         sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
         return SUFR_HIP_E_CONFLICT;
     }
-    if (sd->seq_len >= 0xFFFFFFFFull) {                              // suffix_array.rs:461 selects u64 there
-        sufr_hip_set_error_(ctx, "text_len >= 2^32 - 1 needs 64-bit indices (not built yet)");
+    if (sufr_hip_is_wide_(ctx, sd->seq_len)) {                      // windowed builds are not sharded
+        sufr_hip_set_error_(ctx, "texts of 2^32 - 2^24 bytes and more are built on one GPU (windowed build)");
         return SUFR_HIP_E_UNSUPPORTED;
     }
     uint64_t s = 0;
@@ -639,7 +640,9 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
     const sufr_sequence_data& sd = *sdp;
     const std::string outfile = output_name(a);
     if (path_out && path_out_len) snprintf(path_out, path_out_len, "%s", outfile.c_str());
-    if (sd.seq_len >= 0xFFFFFFFFull || a->has_max_query_len || a->seed_mask) n_ctx = 1;   // single-shard builds
+    if (sufr_hip_is_wide_(ctx0, sd.seq_len))               // windowed build: one GPU, host buffers
+        return sufr_hip_create_from_sequence(ctx0, sdp, a, path_out, path_out_len, stats);
+    if (a->has_max_query_len || a->seed_mask) n_ctx = 1;   // single-shard builds
     const double t0 = now_s();
     std::vector<sufr_shard_info> info(n_ctx);
     std::vector<sufr_hip_stats> st(n_ctx);
@@ -694,11 +697,11 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* s
 {
     if (!ctx || !a || !a->input || !sdp || !sdp->seq) return SUFR_HIP_E_INVALID;
     const sufr_sequence_data& sd = *sdp;
-    if (sd.seq_len < 0xFFFFFFFFull) {
-        // 32-bit indices: SA, LCP and the normalised text stay in HBM after the build and are streamed to the file
+    if (!sufr_hip_is_wide_(ctx, sd.seq_len)) {
+        // one 32-bit window: SA, LCP and the normalised text stay in HBM after the build and are streamed to the file
         return sufr_hip_create_from_sequence_multi(&ctx, 1, sdp, a, path_out, path_out_len, stats);
     }
-    // u64 arrays (suffix_array.rs:461): host buffers
+    // windowed build (sufr_wide.inc), u64 arrays from 2^32 - 1 bytes on (suffix_array.rs:461): host buffers
     char err[512] = {0};
     const std::string outfile = output_name(a);
     if (path_out && path_out_len) snprintf(path_out, path_out_len, "%s", outfile.c_str());
@@ -707,19 +710,19 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* s
         return SUFR_HIP_E_CONFLICT;
     }
     const uint64_t n = sd.seq_len;
-    if (n >= 0xFFFFFFFFull - (1ull << 24)) {                         // before any allocation: the device path's limit
-        sufr_hip_set_error_(ctx, "text_len >= 2^32 - 2^24 needs 64-bit device indices (not built yet)");
-        return SUFR_HIP_E_UNSUPPORTED;
-    }
-    const int width = 8;
+    const int width = n < 0xFFFFFFFFull ? 4 : 8;
     std::vector<uint8_t> norm(n);
     uint64_t s = 0;
     void* sa = malloc((size_t)n * (size_t)width + 8);
     void* lcp = malloc((size_t)n * (size_t)width + 8);
     if (!sa || !lcp) { free(sa); free(lcp); return SUFR_HIP_E_NOMEM; }
-    int rc = sufr_hip_build_u64(ctx, sd.seq, n, build_flags(a), a->has_max_query_len ? a->max_query_len : 0,
-                                a->seed_mask, a->num_partitions, a->random_seed, norm.data(), (uint64_t*)sa,
-                                (uint64_t*)lcp, n, &s, stats);
+    const double t_build = now_s();
+    int rc = width == 4
+        ? sufr_hip_build_u32(ctx, sd.seq, n, build_flags(a), a->has_max_query_len ? a->max_query_len : 0, a->seed_mask,
+                             a->num_partitions, a->random_seed, norm.data(), (uint32_t*)sa, (uint32_t*)lcp, n, &s, stats)
+        : sufr_hip_build_u64(ctx, sd.seq, n, build_flags(a), a->has_max_query_len ? a->max_query_len : 0, a->seed_mask,
+                             a->num_partitions, a->random_seed, norm.data(), (uint64_t*)sa, (uint64_t*)lcp, n, &s, stats);
+    if (stats) stats->host_build_s = (float)(now_s() - t_build);
     if (rc == 0) {
         rc = sufr_write_file(outfile.c_str(), a->is_dna, a->allow_ambiguity, a->ignore_softmask, norm.data(), n,
                              width, sa, lcp, s, a->has_max_query_len, a->max_query_len, a->seed_mask,

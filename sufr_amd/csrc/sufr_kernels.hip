@@ -2105,6 +2105,7 @@ k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t co
 #include "sufr_msd.inc"
 #include "sufr_dbl.inc"
 #include "sufr_launch.inc"
+#include "sufr_wide.inc"
 #include "sufr_capi.inc"
 #include "../../include/sufr_query.h"
 #include "sufr_search.inc"

@@ -103,9 +103,10 @@ class DeviceBuilder:
 
     def sort(self, d_text, *, is_dna=False, allow_ambiguity=False, ignore_softmask=False, raw_text=False,
              shard_index: int = 0, num_shards: int = 1, out_sa=None, out_lcp=None, num_partitions=16,
-             random_seed=42, max_query_len=None, seed_mask=None):
+             random_seed=42, max_query_len=None, seed_mask=None, index_width: int = 4):
         """d_text: uint8 torch tensor on this GPU.  Returns (sa, lcp) int32-typed torch tensors holding
-        u32 values (views of length num_suffixes)."""
+        u32 values (views of length num_suffixes); index_width=8: int64 tensors through sufr_hip_sort_device_u64
+        (texts of 2^32 - 1 bytes and more need it, suffix_array.rs:461)."""
         import torch
         assert d_text.is_cuda and d_text.dtype == torch.uint8 and d_text.is_contiguous()
         # the context's stream is not ordered against torch's: whatever produced d_text must have finished
@@ -113,10 +114,12 @@ class DeviceBuilder:
         n = d_text.numel()
         cap = n if out_sa is None else out_sa.numel()
         if out_sa is None:
-            out_sa = torch.empty(n, dtype=torch.int32, device=d_text.device)
-            out_lcp = torch.empty(n, dtype=torch.int32, device=d_text.device)
+            dt = torch.int32 if index_width == 4 else torch.int64
+            out_sa = torch.empty(n, dtype=dt, device=d_text.device)
+            out_lcp = torch.empty(n, dtype=dt, device=d_text.device)
         ns = C.c_uint64(0)
-        rc = _lib.lib().sufr_hip_sort_device_u32(
+        fn = _lib.lib().sufr_hip_sort_device_u32 if index_width == 4 else _lib.lib().sufr_hip_sort_device_u64
+        rc = fn(
             self.ctx.handle, d_text.data_ptr(), n, _flags(is_dna, allow_ambiguity, ignore_softmask, raw_text),
             int(max_query_len or 0), seed_mask.encode() if seed_mask is not None else None, num_partitions,
             random_seed, shard_index, num_shards, out_sa.data_ptr(), out_lcp.data_ptr(),

@@ -50,13 +50,23 @@ def check_permutation(raw: torch.Tensor, sa: torch.Tensor, *, is_dna: bool, allo
         pos = torch.arange(lo, lo + blk.numel(), device=dev)[m]
         cnt += int(m.sum()); tot += int(pos.sum()); wtot += int((pos * (pos % 1009)).sum())
         xtot ^= int(_xor_reduce(pos * 0x9E3779B1 + 12345))
-    p64 = sa.to(torch.int64) & 0xFFFFFFFF
     M64 = (1 << 64) - 1
-    assert p64.numel() == cnt, f"SA holds {p64.numel()} entries, the text has {cnt} suffix starts"
-    assert int(p64.sum()) == tot, "SA is not a permutation of the eligible positions (sum)"
-    assert (int((p64 * (p64 % 1009)).sum()) & M64) == (wtot & M64), "SA is not a permutation (weighted sum)"
-    assert int(_xor_reduce(p64 * 0x9E3779B1 + 12345)) == xtot, "SA is not a permutation (xor of hashes)"
+    assert sa.numel() == cnt, f"SA holds {sa.numel()} entries, the text has {cnt} suffix starts"
+    stot = 0; swtot = 0; sxtot = 0
+    for lo in range(0, sa.numel(), 1 << 28):               # all sums modulo 2^64, block by block
+        p64 = _values(sa[lo:lo + (1 << 28)])
+        assert int(p64.min()) >= 0 and int(p64.max()) < n, "SA entry outside the text"
+        stot += int(p64.sum()); swtot += int((p64 * (p64 % 1009)).sum())
+        sxtot ^= int(_xor_reduce(p64 * 0x9E3779B1 + 12345))
+    assert (stot & M64) == (tot & M64), "SA is not a permutation of the eligible positions (sum)"
+    assert (swtot & M64) == (wtot & M64), "SA is not a permutation (weighted sum)"
+    assert sxtot == xtot, "SA is not a permutation (xor of hashes)"
     return cnt
+
+
+def _values(v: torch.Tensor) -> torch.Tensor:
+    """u32 values stored in int32 tensors, or int64 tensors as they are (index_width 8)"""
+    return v if v.dtype == torch.int64 else v.to(torch.int64) & 0xFFFFFFFF
 
 
 def _xor_reduce(v: torch.Tensor) -> torch.Tensor:
@@ -117,16 +127,16 @@ def check_sampled_ranks(norm: torch.Tensor, sa: torch.Tensor, lcp: torch.Tensor,
     if deep_samples:
         deep = []
         for lo in range(0, s, 1 << 28):                  # ranks with a long LCP, block by block
-            d = ((lcp[lo:lo + (1 << 28)].to(torch.int64) & 0xFFFFFFFF) >= deep_min_lcp).nonzero()[:, 0] + lo
+            d = (_values(lcp[lo:lo + (1 << 28)]) >= deep_min_lcp).nonzero()[:, 0] + lo
             deep.append(d[d > 0])
         deep = torch.cat(deep)
         if deep.numel():
             sel = torch.randint(0, deep.numel(), (min(deep_samples, deep.numel()),), generator=g, device=dev)
             picks.append(deep[sel]); ndeep = int(sel.numel())
     pick = torch.cat(picks)
-    a = sa[pick - 1].to(torch.int64) & 0xFFFFFFFF
-    b = sa[pick].to(torch.int64) & 0xFFFFFFFF
-    want = lcp[pick].to(torch.int64) & 0xFFFFFFFF
+    a = _values(sa[pick - 1])
+    b = _values(sa[pick])
+    want = _values(lcp[pick])
     for lo in range(0, pick.numel(), 1 << 18):
         got, less = exact_lcp_pairs(norm, a[lo:lo + (1 << 18)], b[lo:lo + (1 << 18)])
         w = want[lo:lo + (1 << 18)]
