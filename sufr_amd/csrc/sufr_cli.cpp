@@ -51,7 +51,8 @@ int usage(FILE* f)
             "  locate|lo    <SUFR> <QUERY>...       Locate sequences [-a] [-m LEN] [-o OUT] [-l] [-v]\n"
             "  extract|ex   <SUFR> <QUERY>...       Extract sequences [-p PREFIX_LEN] [-s SUFFIX_LEN] [-m LEN] [-o OUT] [-l] [-v]\n"
             "  list|ls      <FILE> [RANK]...        List the suffix array [-r] [-s] [-p] [--len LEN] [-n NUM] [-o OUT] [-v]\n"
-            "  summarize|su <SUFR>                  Summarize sufr file\n\n"
+            "  summarize|su <SUFR>                  Summarize sufr file\n"
+            "  count / locate / extract take --device <ID>: the queries are searched as one batch on that GPU\n\n"
             "Global options:\n"
             "  -t, --threads <THREADS>   Accepted for compatibility (the build runs on the GPU)\n"
             "  -l, --log <LOG>           Log level [possible values: info, debug]\n"
@@ -88,6 +89,7 @@ struct QueryArgs {
     bool has_prefix = false, has_suffix = false; uint64_t prefix_len = 0, suffix_len = 0;
     bool show_rank = false, show_suffix = false, show_lcp = false;
     bool has_len = false, has_number = false; uint64_t len = 0, number = 0;
+    int device = -1;                            // --device N: the whole batch of queries is searched on that GPU
 };
 
 // parse_locate_queries (lib.rs:449-466): an argument that names an existing file is read as whitespace-separated queries
@@ -124,16 +126,44 @@ sufr_file* open_or_die(const std::string& path)
     return f;
 }
 
+// Rank range of every query: one by one on the host, or as one batch on a GPU (text + suffix array copied to HBM first:
+// worth it for many queries; the answers are the same, tests/test_gpu_query.py)
+struct Hit { bool found; uint64_t lo, hi; };
+std::vector<Hit> search_all(sufr_file* f, const QueryArgs& a, const std::vector<std::string>& queries)
+{
+    std::vector<Hit> hits(queries.size(), Hit{false, 0, 0});
+    if (a.device < 0) {
+        for (size_t i = 0; i < queries.size(); i++)
+            hits[i].found = sufr_file_search(f, (const uint8_t*)queries[i].data(), queries[i].size(), a.has_mql, a.mql, &hits[i].lo,
+                                             &hits[i].hi) != 0;
+        return hits;
+    }
+    sufr_hip_ctx* ctx = sufr_hip_create(a.device);
+    if (!ctx) { fprintf(stderr, "Error: %s\n", sufr_hip_last_error(nullptr)); exit(1); }
+    sufr_hip_index* ix = nullptr;
+    std::string bytes;
+    std::vector<uint64_t> off(queries.size() + 1, 0), lo(queries.size(), 0), hi(queries.size(), 0);
+    for (size_t i = 0; i < queries.size(); i++) { bytes += queries[i]; off[i + 1] = bytes.size(); }
+    if (sufr_hip_index_load(ctx, f, &ix) != 0 ||
+        sufr_hip_search_batch(ctx, ix, (const uint8_t*)bytes.data(), off.data(), queries.size(), a.has_mql, a.mql, lo.data(), hi.data()) != 0) {
+        fprintf(stderr, "Error: %s\n", sufr_hip_last_error(ctx));
+        exit(1);
+    }
+    for (size_t i = 0; i < queries.size(); i++) hits[i] = Hit{hi[i] > lo[i], lo[i], hi[i]};
+    sufr_hip_index_free(ix);
+    sufr_hip_destroy(ctx);
+    return hits;
+}
+
 int cmd_count(const QueryArgs& a)
 {
     sufr_file* f = open_or_die(a.file);
     OutFile out;
     if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
-    for (const std::string& q : expand_queries(a.positional)) {
-        uint64_t lo = 0, hi = 0;
-        const int hit = sufr_file_search(f, (const uint8_t*)q.data(), q.size(), a.has_mql, a.mql, &lo, &hi);
-        fprintf(out.f, "%s %llu\n", q.c_str(), (unsigned long long)(hit ? hi - lo : 0));
-    }
+    const std::vector<std::string> queries = expand_queries(a.positional);
+    const std::vector<Hit> hits = search_all(f, a, queries);
+    for (size_t i = 0; i < queries.size(); i++)
+        fprintf(out.f, "%s %llu\n", queries[i].c_str(), (unsigned long long)(hits[i].found ? hits[i].hi - hits[i].lo : 0));
     sufr_file_close(f);
     return 0;
 }
@@ -143,9 +173,12 @@ int cmd_locate(const QueryArgs& a)
     sufr_file* f = open_or_die(a.file);
     OutFile out;
     if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
-    for (const std::string& q : expand_queries(a.positional)) {
-        uint64_t lo = 0, hi = 0;
-        if (!sufr_file_search(f, (const uint8_t*)q.data(), q.size(), a.has_mql, a.mql, &lo, &hi)) {
+    const std::vector<std::string> queries = expand_queries(a.positional);
+    const std::vector<Hit> hits = search_all(f, a, queries);
+    for (size_t qi = 0; qi < queries.size(); qi++) {
+        const std::string& q = queries[qi];
+        const uint64_t lo = hits[qi].lo, hi = hits[qi].hi;
+        if (!hits[qi].found) {
             fprintf(stderr, "%s not found\n", q.c_str());
             continue;
         }
@@ -188,9 +221,12 @@ int cmd_extract(const QueryArgs& a)
     if (!out.open(a.output)) { fprintf(stderr, "Error: %s: cannot create\n", a.output.c_str()); return 1; }
     sufr_file_meta m; sufr_file_metadata(f, &m);
     const uint8_t* text = sufr_file_text(f);
-    for (const std::string& q : expand_queries(a.positional)) {
-        uint64_t lo = 0, hi = 0;
-        if (!sufr_file_search(f, (const uint8_t*)q.data(), q.size(), a.has_mql, a.mql, &lo, &hi)) {
+    const std::vector<std::string> queries = expand_queries(a.positional);
+    const std::vector<Hit> hits = search_all(f, a, queries);
+    for (size_t qi = 0; qi < queries.size(); qi++) {
+        const std::string& q = queries[qi];
+        const uint64_t lo = hits[qi].lo, hi = hits[qi].hi;
+        if (!hits[qi].found) {
             fprintf(stderr, "%s not found\n", q.c_str());
             continue;
         }
@@ -361,6 +397,7 @@ int run_query(const std::string& cmd, int argc, char** argv, int first)
         else if (!is_sum && (s == "-o" || s == "--output")) a.output = need(i, "-o");
         else if (!is_list && !is_sum && (s == "-l" || s == "--low-memory")) {}            // access mode only: the file is mapped
         else if (!is_sum && (s == "-v" || s == "--very-low-memory")) {}
+        else if (!is_list && !is_sum && s == "--device") a.device = atoi(need(i, "--device"));
         else if (is_locate && (s == "-a" || s == "--abs")) a.abs = true;
         else if (is_extract && (s == "-p" || s == "--prefix-len")) { a.has_prefix = true; a.prefix_len = strtoull(need(i, "-p"), nullptr, 10); }
         else if (is_extract && (s == "-s" || s == "--suffix-len")) { a.has_suffix = true; a.suffix_len = strtoull(need(i, "-s"), nullptr, 10); }

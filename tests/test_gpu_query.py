@@ -150,3 +150,24 @@ def test_index_of_another_width_or_device_is_refused(ctx):
     x = torch.zeros(16, dtype=torch.uint8, device="cuda")
     with pytest.raises(ValueError):
         DeviceIndex.wrap(ctx, x, torch.zeros(4, dtype=torch.int64, device="cuda"))
+
+
+# the reference's CLI expectations once more, searched as a batch on the GPU (`--device 0`)
+from test_query import EXTRACT_CASES, LOCATE_CASES, run
+
+
+def test_cli_count_on_the_device():
+    assert run("count", "--device", 0, EXP / "1.sufr", "AC", "X", "GT").stdout == "AC 2\nX 0\nGT 2\n"
+
+
+@pytest.mark.parametrize("case", range(len(LOCATE_CASES)))
+def test_cli_locate_on_the_device(case):
+    path, queries, opts, expected = LOCATE_CASES[case]
+    assert run("locate", path, "--device", 0, *opts, *queries).stdout == (EXP / expected).read_text()
+
+
+@pytest.mark.parametrize("case", range(len(EXTRACT_CASES)))
+def test_cli_extract_on_the_device(case):
+    path, queries, opts, lines, err = EXTRACT_CASES[case]
+    r = run("extract", path, "--device", 0, *opts, *queries)
+    assert r.stdout == "".join(l + "\n" for l in lines) and r.stderr == err
