@@ -208,6 +208,40 @@ def e2e_create_sharded(text, starts, flags: dict, partitions: int, rank: int, wo
             shutil.rmtree(tmp, ignore_errors=True)
 
 
+def search_rate(builder, norm, sa, dev, num_queries: int = 4_000_000, query_len: int = 32):
+    """Query side, never part of `value`: the suffix array of the last timed step is wrapped in
+    place and searched for substrings of the text (every tenth with one changed symbol)."""
+    try:
+        from sufr_amd import DeviceIndex
+        n = norm.numel()
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        at = torch.randint(0, max(1, n - query_len - 1), (num_queries,), generator=g, device=dev)
+        qb = norm[(at[:, None] + torch.arange(query_len, device=dev)[None, :]).reshape(-1)].contiguous()
+        flip = torch.arange(0, num_queries, 10, device=dev) * query_len
+        qb[flip] = norm[torch.randint(0, n, (flip.numel(),), generator=g, device=dev)]
+        off = (torch.arange(num_queries + 1, device=dev, dtype=torch.int64) * query_len).contiguous()
+        ix = DeviceIndex.wrap(builder.ctx, norm, sa)
+        ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            lo, hi = ix.search_device(qb, off)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        found = float((hi > lo).float().mean())
+        # the answer against the text: both ends of every sampled range start with the query
+        pick = torch.randint(0, num_queries, (100_000,), generator=g, device=dev)
+        pick = pick[hi[pick] > lo[pick]]
+        q = qb.view(num_queries, query_len)[pick]
+        for ranks in (lo[pick], hi[pick] - 1):
+            pos = (sa[ranks].to(torch.int64) & 0xFFFFFFFF)[:, None] + torch.arange(query_len, device=dev)[None, :]
+            assert bool(((pos < n) & (norm[pos.clamp(max=n - 1)] == q)).all()), "device search: range end does not match"
+        ix.close()
+        med = sorted(ms)[1]
+        return {"kernel": "k_search_batch", "queries": num_queries, "query_len": query_len, "ms": med,
+                "queries_per_s": num_queries / (med * 1e-3), "found": found, "checked_ranges": int(pick.numel())}
+    except Exception as e:                       # the headline line must not depend on this
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +256,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check of the timed run's arrays (N = 1, outside the timed region: permutation of "
                          "the suffix starts, order and exact unbounded LCP on 1.1e6 sampled ranks)")
+    ap.add_argument("--no-search", action="store_true",
+                    help="skip the query-side figure (batched device search on the arrays of the last step; outside the timed region)")
     ap.add_argument("--backend", default=os.environ.get("SUFR_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing N>1 on one GPU)")
     ap.add_argument("--share-device", action="store_true",
@@ -344,6 +380,7 @@ def main():
 
     s_total = totals["s_total"]
     verified = None
+    search = None
     if world == 1 and not args.no_verify:
         # outside the timed region: the arrays of the last timed step against the text (sufr_amd/verify.py)
         from sufr_amd import verify
@@ -356,6 +393,8 @@ def main():
         verified = verify.check_sampled_ranks(norm, sa, lcp, samples=1_000_000, deep_samples=100_000)
         verified["what"] = ("SA = permutation of the suffix starts (count, sum, weighted sum, xor of hashes); order and "
                             "exact unbounded LCP on sampled adjacent ranks, deep_ranks of them with LCP >= 64")
+        if not args.no_search:
+            search = search_rate(builder, norm, sa, dev)
         del norm
 
     e2e_multi = None
@@ -397,6 +436,8 @@ def main():
             "device_ms": avg,
             "verified": verified,
         }
+        if search is not None:
+            out["search"] = search
         if world == 1 and not args.no_cpu_baseline:
             sample_bases = min(bases, 400_000_000)
             out["cpu_baseline"] = cpu_baseline(text[:sample_bases].cpu().numpy(), flags, partitions)
