@@ -115,6 +115,9 @@ def test_medium_windowed_build_properties():
 def test_text_beyond_32_bits():
     """4.4e9 bytes (> 2^32): random DNA with repeats planted across the window boundary, u64 arrays.  Checked without a
     second build: SA is a permutation of the suffix starts, sampled neighbours are in order with the exact LCP."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                                  # ~200 GB of HBM: nothing of earlier tests may linger in torch's cache
     n = 4_400_000_001
     dev = "cuda"
     g = torch.Generator(device=dev); g.manual_seed(8)
@@ -142,3 +145,5 @@ def test_text_beyond_32_bits():
     assert res["deep_ranks"] > 0 and res["max_lcp_checked"] >= 40_000
     print(f"4.4e9-byte text: {st.ms_total:.0f} ms device total, {res}")
     db.close()
+    del x, sa, lcp
+    torch.cuda.empty_cache()
