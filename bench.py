@@ -208,7 +208,7 @@ def e2e_create_sharded(text, starts, flags: dict, partitions: int, rank: int, wo
             shutil.rmtree(tmp, ignore_errors=True)
 
 
-def search_rate(builder, norm, sa, dev, num_queries: int = 4_000_000, query_len: int = 32):
+def search_rate(builder, norm, sa, dev, is_dna: bool, num_queries: int = 4_000_000, query_len: int = 32):
     """Query side, never part of `value`: the suffix array of the last timed step is wrapped in
     place and searched for substrings of the text (every tenth with one changed symbol)."""
     try:
@@ -220,7 +220,7 @@ def search_rate(builder, norm, sa, dev, num_queries: int = 4_000_000, query_len:
         flip = torch.arange(0, num_queries, 10, device=dev) * query_len
         qb[flip] = norm[torch.randint(0, n, (flip.numel(),), generator=g, device=dev)]
         off = (torch.arange(num_queries + 1, device=dev, dtype=torch.int64) * query_len).contiguous()
-        ix = DeviceIndex.wrap(builder.ctx, norm, sa)
+        ix = DeviceIndex.wrap(builder.ctx, norm, sa, is_dna=is_dna)
         ms = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -394,7 +394,7 @@ def main():
         verified["what"] = ("SA = permutation of the suffix starts (count, sum, weighted sum, xor of hashes); order and "
                             "exact unbounded LCP on sampled adjacent ranks, deep_ranks of them with LCP >= 64")
         if not args.no_search:
-            search = search_rate(builder, norm, sa, dev)
+            search = search_rate(builder, norm, sa, dev, bool(flags.get("is_dna", False)))
         del norm
 
     e2e_multi = None

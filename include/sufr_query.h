@@ -68,14 +68,19 @@ int sufr_file_search(const sufr_file *f, const uint8_t *query, size_t query_len,
  * sufr_hip_index_wrap   wraps arrays that are already on the device -- e.g. the normalized text handed to
  *                       sufr_hip_sort_device_u32 and the SA it produced: build, then query, without leaving HBM.
  *                       The caller keeps ownership of d_text / d_sa.  seed_mask: the "1101"-style string or NULL.
+ *                       flags: SUFR_HIP_FLAG_DNA as at build time; SUFR_HIP_FLAG_NO_PREFIX_TABLE skips the table below.
+ * Both build a prefix table next to the arrays: the rank range of every string of k symbols (ACGT for DNA, k = 14 on a
+ * genome: 2 GB; otherwise the frequent bytes of the text), so that a query starts its two binary searches inside the
+ * few ranks that share its first k symbols.  Answers do not depend on it.
  * Queries are the concatenated query bytes plus num_queries + 1 offsets (query i = bytes [offsets[i], offsets[i+1])).
  * rank_lo / rank_hi receive the half-open rank range per query, lo == hi == 0 when the query does not occur.
  * _batch takes host buffers and returns when the answers are in rank_lo / rank_hi; _batch_device takes device buffers
  * and only enqueues on the context's stream. */
 typedef struct sufr_hip_index sufr_hip_index;
 int  sufr_hip_index_load(sufr_hip_ctx *ctx, const sufr_file *f, sufr_hip_index **out);
+#define SUFR_HIP_FLAG_NO_PREFIX_TABLE 0x100u
 int  sufr_hip_index_wrap(sufr_hip_ctx *ctx, const void *d_text, uint64_t text_len, const void *d_sa, uint64_t num_suffixes,
-                         uint64_t built_max_query_len, const char *seed_mask, sufr_hip_index **out);
+                         uint32_t flags, uint64_t built_max_query_len, const char *seed_mask, sufr_hip_index **out);
 void sufr_hip_index_free(sufr_hip_index *ix);
 int  sufr_hip_search_batch(sufr_hip_ctx *ctx, const sufr_hip_index *ix, const uint8_t *queries, const uint64_t *offsets,
                            uint64_t num_queries, int has_max_query_len, uint64_t max_query_len, uint64_t *rank_lo,

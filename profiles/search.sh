@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; export TMPDIR=/tmp
 OUT=$R/gpurun_out/search; mkdir -p $OUT
 timeout 1500 python -m pytest tests/test_gpu_query.py -x -q 2>&1 | tail -5 > $OUT/tests.txt
 timeout 600 python profiles/search_bench.py 1e8 1e7 32 2>&1 | grep -v amdgpu.ids > $OUT/bench_100m.txt
+SEARCH_NO_TABLE=1 timeout 900 python profiles/search_bench.py 3.1e9 1.6e7 32 2>&1 | grep "^device" > $OUT/bench_3g_no_table.txt
 cd /tmp
 rm -rf /tmp/prof_s; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -- python3 $R/profiles/search_bench.py 3.1e9 1.6e7 32 > $OUT/bench_3g.txt 2>&1
 grep "^device\|^host" $OUT/bench_3g.txt > $OUT/bench_3g.tmp; mv $OUT/bench_3g.tmp $OUT/bench_3g.txt
@@ -23,4 +24,4 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 done
 python3 $R/profiles/summarize_pmc.py $OUT/pmc_search.csv /tmp/prof_spmc*/
 grep k_search_batch $OUT/pmc_search.csv > $OUT/pmc_search_kernel.csv
-cat $OUT/tests.txt $OUT/bench_100m.txt $OUT/bench_3g.txt $OUT/kernel_stats_search.txt $OUT/pmc_search_kernel.csv
+cat $OUT/tests.txt $OUT/bench_100m.txt $OUT/bench_3g_no_table.txt $OUT/bench_3g.txt $OUT/kernel_stats_search.txt $OUT/pmc_search_kernel.csv

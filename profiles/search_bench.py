@@ -25,7 +25,7 @@ norm = torch.where((x >= 97) & (x <= 122), x - 32, x)        # sufr_builder.rs:1
 del x
 sa, lcp = db.sort(norm, is_dna=True)
 del lcp
-ix = sufr_amd.DeviceIndex.wrap(db.ctx, norm, sa)
+ix = sufr_amd.DeviceIndex.wrap(db.ctx, norm, sa, is_dna=True, prefix_table=not os.environ.get("SEARCH_NO_TABLE"))
 g = torch.Generator(device=dev); g.manual_seed(1)
 at = torch.randint(0, n - ql - 1, (nq,), generator=g, device=dev)
 qb = norm[(at[:, None] + torch.arange(ql, device=dev)[None, :]).reshape(-1)].contiguous()
@@ -42,7 +42,7 @@ with torch.cuda.stream(stream):
         e1.record(stream)
         stream.synchronize()
         ms = e0.elapsed_time(e1)
-        print(f"device: text {n:,} suffixes {sa.numel():,} queries {nq:,} x {ql}: {ms:.2f} ms  {nq / ms / 1e3:.1f} M queries/s  "
+        print(f"device{' (no prefix table)' if os.environ.get('SEARCH_NO_TABLE') else ''}: text {n:,} suffixes {sa.numel():,} queries {nq:,} x {ql}: {ms:.2f} ms  {nq / ms / 1e3:.1f} M queries/s  "
               f"found {(hi > lo).float().mean().item():.3f}  mean count {(hi - lo).float().mean().item():.2f}", flush=True)
 if n <= 200_000_000:
     with tempfile.TemporaryDirectory() as d:
@@ -59,6 +59,6 @@ if n <= 200_000_000:
         t0 = time.perf_counter()
         for i in range(m):
             hit = lib.sufr_file_search(f._h, qh[i * ql:(i + 1) * ql], ql, 0, 0, C.byref(a), C.byref(b))
-            assert (a.value, b.value) == (lo_h[i], hi_h[i]) if hit else hi_h[i] == lo_h[i]
+            assert ((a.value, b.value) == (lo_h[i], hi_h[i])) if hit else (hi_h[i] == lo_h[i]), (i, hit, a.value, b.value, lo_h[i], hi_h[i])
         dt = time.perf_counter() - t0
         print(f"host (1 thread, ctypes loop): {m:,} queries in {dt:.2f} s  {m / dt / 1e6:.3f} M queries/s, equal to the device answers")

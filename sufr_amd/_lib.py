@@ -60,6 +60,7 @@ class ShardInfo(C.Structure):
 
 
 FLAG_DNA, FLAG_ALLOW_AMBIGUITY, FLAG_IGNORE_SOFTMASK, FLAG_RAW_TEXT = 1, 2, 4, 8
+FLAG_NO_PREFIX_TABLE = 0x100      # sufr_hip_index_wrap only
 
 # every symbol include/sufr_hip.h declares
 EXPORTS = [
@@ -164,7 +165,7 @@ def lib() -> C.CDLL:
     L.sufr_file_search.argtypes = [vp, cp, C.c_size_t, C.c_int, u64, C.POINTER(u64), C.POINTER(u64)]
     L.sufr_file_search.restype = C.c_int
     L.sufr_hip_index_load.argtypes = [vp, vp, C.POINTER(vp)]; L.sufr_hip_index_load.restype = C.c_int
-    L.sufr_hip_index_wrap.argtypes = [vp, vp, u64, vp, u64, u64, cp, C.POINTER(vp)]; L.sufr_hip_index_wrap.restype = C.c_int
+    L.sufr_hip_index_wrap.argtypes = [vp, vp, u64, vp, u64, u32, u64, cp, C.POINTER(vp)]; L.sufr_hip_index_wrap.restype = C.c_int
     L.sufr_hip_index_free.argtypes = [vp]; L.sufr_hip_index_free.restype = None
     L.sufr_hip_search_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]; L.sufr_hip_search_batch.restype = C.c_int
     L.sufr_hip_search_batch_device.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]

@@ -259,12 +259,16 @@ class DeviceIndex:
         return cls(ctx, h)
 
     @classmethod
-    def wrap(cls, ctx: Context, text, sa, max_query_len: int = 0, seed_mask: Optional[str] = None) -> "DeviceIndex":
+    def wrap(cls, ctx: Context, text, sa, max_query_len: int = 0, seed_mask: Optional[str] = None, is_dna: bool = False,
+             prefix_table: bool = True) -> "DeviceIndex":
         import torch
         if not (text.is_cuda and sa.is_cuda and text.dtype == torch.uint8 and sa.dtype in (torch.int32, torch.uint32)):
             raise ValueError("wrap() takes a uint8 text and a 32-bit suffix array on the GPU")
         h = C.c_void_p()
-        ctx.check(lib().sufr_hip_index_wrap(ctx.handle, text.data_ptr(), text.numel(), sa.data_ptr(), sa.numel(),
+        from ._lib import FLAG_DNA, FLAG_NO_PREFIX_TABLE
+        torch.cuda.current_stream(text.device).synchronize()      # the table is built from the arrays right away
+        flags = (FLAG_DNA if is_dna else 0) | (0 if prefix_table else FLAG_NO_PREFIX_TABLE)
+        ctx.check(lib().sufr_hip_index_wrap(ctx.handle, text.data_ptr(), text.numel(), sa.data_ptr(), sa.numel(), flags,
                                             max_query_len, seed_mask.encode() if seed_mask else None, C.byref(h)))
         return cls(ctx, h, keep=(text, sa))
 
