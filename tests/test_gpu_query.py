@@ -125,6 +125,19 @@ def test_build_then_query_without_leaving_the_device(ctx, tmp_path):
     assert 0.6 < found.mean() < 1.0
     assert int((hi - lo).max()) > 400                           # the poly-A run
     check_range_properties(text, sa_h, qb, off, lo, hi, rng.integers(0, nq, 20_000))
+    # the prefix table (k = 13 here) changes no answer: the same batch without it, with -m below / at / above k, and
+    # queries that start with symbols outside the table alphabet or are shorter than k
+    plain = DeviceIndex.wrap(db.ctx, x, sa, prefix_table=False)
+    plo, phi = plain.search_packed(qb, off)
+    assert np.array_equal(plo, lo) and np.array_equal(phi, hi)
+    odd = qb.copy()
+    odd[rng.integers(0, odd.size, nq // 2)] = ord("N")
+    short_off = np.zeros(nq + 1, dtype=np.uint64); short_off[1:] = np.cumsum(np.minimum(lens, rng.integers(1, 16, nq)))
+    for qbytes, offsets, mql in ((odd, off, None), (qb, short_off, None), (qb, off, 5), (qb, off, 13), (qb, off, 20)):
+        a = ix.search_packed(qbytes[:int(offsets[-1])], offsets, mql)
+        b = plain.search_packed(qbytes[:int(offsets[-1])], offsets, mql)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), mql
+    plain.close()
     # device buffers in, device buffers out
     dlo, dhi = ix.search_device(torch.from_numpy(qb).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev))
     assert np.array_equal(dlo.cpu().numpy().astype(np.uint64), lo) and np.array_equal(dhi.cpu().numpy().astype(np.uint64), hi)
