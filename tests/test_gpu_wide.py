@@ -53,6 +53,21 @@ def test_windowed_build_equals_oracle(oracle, window, margin, index_width, flags
     assert st.num_suffixes == sa.size and st.text_len == t.size
 
 
+@pytest.mark.parametrize("index_width", [4, 8])
+def test_two_windows_with_a_one_sided_repeat(oracle, index_width):
+    """Two windows where thousands of suffixes of one window fall between two neighbouring suffixes of the other (a
+    homopolymer and a tandem array that live in the second window only): the ranges above the sequential-merge limit
+    take the binary-search path"""
+    rng = np.random.default_rng(6)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = np.concatenate([acgt[rng.integers(0, 4, 30_000)], np.full(12_000, ord("A"), dtype=np.uint8), acgt[rng.integers(0, 4, 3_000)],
+                        np.resize(np.frombuffer(b"ACG", dtype=np.uint8), 9_000), acgt[rng.integers(0, 4, 6_000)],
+                        np.frombuffer(b"$", dtype=np.uint8)])
+    want_sa, want_lcp, _ = oracle.build(t, is_dna=True)
+    sa, lcp, _ = build(torch.from_numpy(t).cuda(), 30_000, 4_000, index_width, is_dna=True)
+    assert np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
+
+
 def test_windowed_build_of_raw_soft_masked_text(oracle):
     rng = np.random.default_rng(2)
     t = repeat_text(50_000, 3, 300, 30)
