@@ -110,6 +110,15 @@ def lib() -> C.CDLL:
     if not LIB_PATH.exists():
         raise SufrHipError(-2, f"{LIB_PATH} is missing: build it with sufr_amd.build_extension() "
                                "(there is no CPU fallback)")
+    # PyTorch wheels bundle their own HIP runtime; a process that loads this library first (/opt/rocm's runtime) and
+    # torch afterwards ends up with two runtimes, and the second one to initialise finds no device.  Whoever uses the
+    # Python binding next to torch gets torch's runtime for both: import it first when it is installed.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(str(LIB_PATH))
     vp, u64, u32, cp = C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p
     L.sufr_hip_abi_version.restype = C.c_int
