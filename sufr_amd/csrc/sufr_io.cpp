@@ -6,6 +6,7 @@
 //   text normalisation      libsufr/src/sufr_builder.rs:144-160
 //   SufrBuilder::write      libsufr/src/sufr_builder.rs:817-918   (.sufr version 6)
 //   sufr::create            sufr/src/lib.rs:321-371, width rule suffix_array.rs:460-470
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
@@ -391,6 +392,91 @@ uint64_t sufr_hip_lcp_pair(const uint8_t* t, uint64_t n, uint64_t a, uint64_t b)
     return k;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bzip2 / xz input (needletail inflates both transparently in the reference, util.rs:55).  The image ships the run-time
+// libraries without their headers, so the two stable C interfaces are declared here and resolved with dlopen; a box
+// without the library gets a message that names it.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct BzStream {                      // bz_stream of bzlib.h (libbz2 1.0)
+    char* next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+    char* next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+    void* state; void* (*bzalloc)(void*, int, int); void (*bzfree)(void*, void*); void* opaque;
+};
+struct LzmaStream {                    // lzma_stream of lzma/base.h (liblzma 5.x)
+    const uint8_t* next_in; size_t avail_in; uint64_t total_in;
+    uint8_t* next_out; size_t avail_out; uint64_t total_out;
+    const void* allocator; void* internal; void* reserved_ptr[4]; uint64_t reserved_int1, reserved_int2;
+    size_t reserved_int3, reserved_int4; int reserved_enum1, reserved_enum2;
+};
+
+bool inflate_bzip2(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::string& why)
+{
+    void* h = dlopen("libbz2.so.1.0", RTLD_NOW);
+    if (!h) h = dlopen("libbz2.so.1", RTLD_NOW);
+    if (!h) { why = "bzip2 input needs libbz2.so.1.0, which this machine does not have"; return false; }
+    auto init = (int (*)(BzStream*, int, int))dlsym(h, "BZ2_bzDecompressInit");
+    auto run = (int (*)(BzStream*))dlsym(h, "BZ2_bzDecompress");
+    auto fini = (int (*)(BzStream*))dlsym(h, "BZ2_bzDecompressEnd");
+    if (!init || !run || !fini) { why = "libbz2 lacks the BZ2_bzDecompress interface"; dlclose(h); return false; }
+    out.resize(len * 5 + (1u << 20));
+    size_t have = 0, at = 0;
+    bool ok = true;
+    while (ok && at < len) {                                     // concatenated streams, like bzcat
+        BzStream st;
+        memset(&st, 0, sizeof st);
+        if (init(&st, 0, 0) != 0) { why = "BZ2_bzDecompressInit failed"; ok = false; break; }
+        int rc = 0;
+        while (rc == 0) {
+            if (out.size() - have < (1u << 20)) out.resize(out.size() * 2);
+            const size_t in_left = len - at, room = out.size() - have;
+            st.next_in = (char*)src + at; st.avail_in = (unsigned)(in_left > (1u << 30) ? (1u << 30) : in_left);
+            st.next_out = (char*)out.data() + have; st.avail_out = (unsigned)(room > (1u << 30) ? (1u << 30) : room);
+            const unsigned in0 = st.avail_in, out0 = st.avail_out;
+            rc = run(&st);
+            at += in0 - st.avail_in; have += out0 - st.avail_out;
+            if (rc == 0 && in0 == st.avail_in && out0 == st.avail_out) { rc = -7; }      // no progress: truncated input
+        }
+        fini(&st);
+        if (rc != 4) { why = "corrupt or truncated bzip2 stream"; ok = false; }             // BZ_STREAM_END
+        while (ok && at < len && (src[at] == 0)) at++;                                      // padding between streams
+        if (ok && at < len && !(len - at >= 3 && src[at] == 'B' && src[at + 1] == 'Z' && src[at + 2] == 'h')) break;   // trailing garbage: ignored
+    }
+    dlclose(h);
+    out.resize(ok ? have : 0);
+    return ok;
+}
+
+bool inflate_xz(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::string& why)
+{
+    void* h = dlopen("liblzma.so.5", RTLD_NOW);
+    if (!h) { why = "xz input needs liblzma.so.5, which this machine does not have"; return false; }
+    auto init = (int (*)(LzmaStream*, uint64_t, uint32_t))dlsym(h, "lzma_stream_decoder");
+    auto run = (int (*)(LzmaStream*, int))dlsym(h, "lzma_code");
+    auto fini = (void (*)(LzmaStream*))dlsym(h, "lzma_end");
+    if (!init || !run || !fini) { why = "liblzma lacks the lzma_stream_decoder interface"; dlclose(h); return false; }
+    LzmaStream st;
+    memset(&st, 0, sizeof st);
+    if (init(&st, UINT64_MAX, 0x08u /* LZMA_CONCATENATED */) != 0) { why = "lzma_stream_decoder failed"; dlclose(h); return false; }
+    out.resize(len * 5 + (1u << 20));
+    st.next_in = src; st.avail_in = len;
+    size_t have = 0;
+    int rc = 0;
+    while (rc == 0) {
+        if (out.size() - have < (1u << 20)) out.resize(out.size() * 2);
+        st.next_out = out.data() + have; st.avail_out = out.size() - have;
+        const size_t out0 = st.avail_out;
+        rc = run(&st, st.avail_in ? 0 /* LZMA_RUN */ : 3 /* LZMA_FINISH */);
+        have += out0 - st.avail_out;
+    }
+    fini(&st);
+    dlclose(h);
+    if (rc != 1) { why = "corrupt or truncated xz stream"; out.clear(); return false; }      // LZMA_STREAM_END
+    out.resize(have);
+    return true;
+}
+}  // namespace
+
 int sufr_read_sequence_file(const char* path, uint8_t delimiter, sufr_sequence_data* out, char* err,
                             size_t errlen)
 {
@@ -428,10 +514,13 @@ int sufr_read_sequence_file(const char* path, uint8_t delimiter, sufr_sequence_d
         inflated.resize(have);
         p = inflated.data();
         end = inflated.data() + inflated.size();
-    } else if (fv.size >= 3 && ((fv.data[0] == 'B' && fv.data[1] == 'Z' && fv.data[2] == 'h') ||
-                                (fv.data[0] == 0xfd && fv.data[1] == '7' && fv.data[2] == 'z'))) {
-        put_err(err, errlen, std::string(path) + ": bzip2 / xz input is not supported (gzip and plain text are)");
-        return SUFR_HIP_E_UNSUPPORTED;
+    } else if (fv.size >= 3 && fv.data[0] == 'B' && fv.data[1] == 'Z' && fv.data[2] == 'h') {
+        if (!inflate_bzip2(fv.data, fv.size, inflated, why)) { put_err(err, errlen, std::string(path) + ": " + why); return SUFR_HIP_E_IO; }
+        p = inflated.data(); end = inflated.data() + inflated.size();
+    } else if (fv.size >= 6 && fv.data[0] == 0xfd && fv.data[1] == '7' && fv.data[2] == 'z' && fv.data[3] == 'X' && fv.data[4] == 'Z' &&
+               fv.data[5] == 0) {
+        if (!inflate_xz(fv.data, fv.size, inflated, why)) { put_err(err, errlen, std::string(path) + ": " + why); return SUFR_HIP_E_IO; }
+        p = inflated.data(); end = inflated.data() + inflated.size();
     }
     while (p < end && (*p == '\n' || *p == '\r' || *p == ' ' || *p == '\t')) p++;
     if (p >= end) { put_err(err, errlen, std::string(path) + ": empty sequence file"); return SUFR_HIP_E_IO; }

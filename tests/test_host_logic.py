@@ -94,9 +94,9 @@ def test_parallel_fasta_reader_equals_the_serial_one(tmp_path, monkeypatch):
     assert len(par.sequence_names) == 300 and par.seq.endswith(b"$")
 
 
-def test_gzip_input_reads_like_plain_text(tmp_path):
-    """needletail (the reference's reader) inflates gzip transparently; so does this reader, including
-    concatenated members.  bzip2 / xz are refused loudly."""
+def test_compressed_input_reads_like_plain_text(tmp_path):
+    """needletail (the reference's reader, util.rs:55) inflates gzip, bzip2 and xz transparently; so does this reader,
+    concatenated members / streams included; damaged streams are refused with a message."""
     import gzip
     plain = (GOLDEN / "inputs" / "long_dna_sequence.fa").read_bytes()
     want = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "long_dna_sequence.fa")
@@ -110,11 +110,24 @@ def test_gzip_input_reads_like_plain_text(tmp_path):
         assert (got.seq, got.start_positions, got.sequence_names) == (want.seq, want.start_positions,
                                                                         want.sequence_names)
     import bz2
-    bad = tmp_path / "c.fa.bz2"
-    bad.write_bytes(bz2.compress(plain))
-    with pytest.raises(sufr_amd.SufrHipError) as e:
-        sufr_amd.read_sequence_file(bad)
-    assert "not supported" in str(e.value)
+    import lzma
+    cases = {"c.fa.bz2": bz2.compress(plain), "d.fa.bz2": bz2.compress(plain[:half]) + bz2.compress(plain[half:]),
+             "e.fa.xz": lzma.compress(plain), "f.fa.xz": lzma.compress(plain[:half]) + lzma.compress(plain[half:]),
+             "g.fa.xz": lzma.compress(plain, preset=9 | lzma.PRESET_EXTREME)}
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        got = sufr_amd.read_sequence_file(tmp_path / name)
+        assert (got.seq, got.start_positions, got.sequence_names) == (want.seq, want.start_positions, want.sequence_names), name
+    big = b">r\n" + bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(1).integers(0, 4, 3_000_000)]) + b"\n"
+    for name, data in (("h.fa.bz2", bz2.compress(big)), ("i.fa.xz", lzma.compress(big))):   # output far beyond the first buffer
+        (tmp_path / name).write_bytes(data)
+        assert sufr_amd.read_sequence_file(tmp_path / name).seq == big[3:-1] + b"$"
+    for name, data in (("j.fa.bz2", bz2.compress(plain)[:-20]), ("k.fa.xz", lzma.compress(plain)[:-20]),
+                       ("l.fa.bz2", b"BZh9" + b"\x00" * 40)):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(sufr_amd.SufrHipError) as e:
+            sufr_amd.read_sequence_file(tmp_path / name)
+        assert "corrupt or truncated" in str(e.value), name
 
 
 def test_empty_input_dies():  # cli.rs:103-110
