@@ -59,6 +59,12 @@ uint64_t sufr_file_sequence_of(const sufr_file *f, uint64_t pos);
 int sufr_file_search(const sufr_file *f, const uint8_t *query, size_t query_len, int has_max_query_len,
                      uint64_t max_query_len, uint64_t *rank_lo, uint64_t *rank_hi);
 
+/* A batch on the host: `threads` workers share the queries (0: one per core), the reference's rayon loop over queries
+ * (sufr_file.rs:760-800).  Queries are the concatenated bytes plus num_queries + 1 offsets; rank_lo / rank_hi receive
+ * the half-open range per query, lo == hi == 0 when the query does not occur. */
+int sufr_file_search_batch(const sufr_file *f, const uint8_t *queries, const uint64_t *offsets, uint64_t num_queries,
+                           int has_max_query_len, uint64_t max_query_len, uint64_t *rank_lo, uint64_t *rank_hi, int threads);
+
 /* ---- the same search for a batch of queries, on the GPU ---------------------------------------------------------
  * Replaces the rayon loop of SuffixArray::count / locate (libsufr/src/suffix_array.rs:181-236, 340-366;
  * sufr_file.rs:760-800): text and suffix array are resident in HBM, one launch answers the batch, one lane per

@@ -52,13 +52,15 @@ if n <= 200_000_000:
         assert lib.sufr_write_file(path.encode(), 1, 0, 0, text_h.ctypes.data, n, 4, sa_h.ctypes.data, lcp_h.ctypes.data, sa_h.size,
                                    0, 0, None, starts.ctypes.data, 1, names, err, len(err)) == 0
         f = sufr_amd.SufrFile(path)
-        m = min(nq, 200_000)
-        qh = qb[:m * ql].cpu().numpy().tobytes()
-        lo_h = lo[:m].cpu().numpy(); hi_h = hi[:m].cpu().numpy()
-        a, b = C.c_uint64(), C.c_uint64()
-        t0 = time.perf_counter()
-        for i in range(m):
-            hit = lib.sufr_file_search(f._h, qh[i * ql:(i + 1) * ql], ql, 0, 0, C.byref(a), C.byref(b))
-            assert ((a.value, b.value) == (lo_h[i], hi_h[i])) if hit else (hi_h[i] == lo_h[i]), (i, hit, a.value, b.value, lo_h[i], hi_h[i])
-        dt = time.perf_counter() - t0
-        print(f"host (1 thread, ctypes loop): {m:,} queries in {dt:.2f} s  {m / dt / 1e6:.3f} M queries/s, equal to the device answers")
+        m = min(nq, 2_000_000)
+        qh = qb[:m * ql].cpu().numpy()
+        offs = (np.arange(m + 1, dtype=np.uint64) * ql)
+        lo_h = lo[:m].cpu().numpy().astype(np.uint64); hi_h = hi[:m].cpu().numpy().astype(np.uint64)
+        a = np.zeros(m, dtype=np.uint64); b = np.zeros(m, dtype=np.uint64)
+        for threads in (1, 16, os.cpu_count() or 1):
+            mm = m if threads > 1 else m // 10
+            t0 = time.perf_counter()
+            lib.sufr_file_search_batch(f._h, qh.ctypes.data, offs.ctypes.data, mm, 0, 0, a.ctypes.data, b.ctypes.data, threads)
+            dt = time.perf_counter() - t0
+            assert np.array_equal(a[:mm], lo_h[:mm]) and np.array_equal(b[:mm], hi_h[:mm])
+            print(f"host (sufr_file_search_batch, {threads} threads): {mm:,} queries in {dt:.2f} s  {mm / dt / 1e6:.3f} M queries/s, equal to the device answers", flush=True)

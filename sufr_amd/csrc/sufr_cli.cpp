@@ -54,7 +54,7 @@ int usage(FILE* f)
             "  summarize|su <SUFR>                  Summarize sufr file\n"
             "  count / locate / extract take --device <ID>: the queries are searched as one batch on that GPU\n\n"
             "Global options:\n"
-            "  -t, --threads <THREADS>   Accepted for compatibility (the build runs on the GPU)\n"
+            "  -t, --threads <THREADS>   Host workers of count / locate / extract [default: one per core]; create runs on the GPU\n"
             "  -l, --log <LOG>           Log level [possible values: info, debug]\n"
             "      --log-file <FILE>     Log file\n"
             "      --device <ID>         HIP device ordinal [default: 0]\n"
@@ -90,6 +90,7 @@ struct QueryArgs {
     bool show_rank = false, show_suffix = false, show_lcp = false;
     bool has_len = false, has_number = false; uint64_t len = 0, number = 0;
     int device = -1;                            // --device N: the whole batch of queries is searched on that GPU
+    int threads = 0;                            // -t/--threads (global option, sufr/src/lib.rs:29-46): host search workers
 };
 
 // parse_locate_queries (lib.rs:449-466): an argument that names an existing file is read as whitespace-separated queries
@@ -132,18 +133,17 @@ struct Hit { bool found; uint64_t lo, hi; };
 std::vector<Hit> search_all(sufr_file* f, const QueryArgs& a, const std::vector<std::string>& queries)
 {
     std::vector<Hit> hits(queries.size(), Hit{false, 0, 0});
+    std::string bytes;
+    std::vector<uint64_t> off(queries.size() + 1, 0), lo(queries.size(), 0), hi(queries.size(), 0);
+    for (size_t i = 0; i < queries.size(); i++) { bytes += queries[i]; off[i + 1] = bytes.size(); }
     if (a.device < 0) {
-        for (size_t i = 0; i < queries.size(); i++)
-            hits[i].found = sufr_file_search(f, (const uint8_t*)queries[i].data(), queries[i].size(), a.has_mql, a.mql, &hits[i].lo,
-                                             &hits[i].hi) != 0;
+        sufr_file_search_batch(f, (const uint8_t*)bytes.data(), off.data(), queries.size(), a.has_mql, a.mql, lo.data(), hi.data(), a.threads);
+        for (size_t i = 0; i < queries.size(); i++) hits[i] = Hit{hi[i] > lo[i], lo[i], hi[i]};
         return hits;
     }
     sufr_hip_ctx* ctx = sufr_hip_create(a.device);
     if (!ctx) { fprintf(stderr, "Error: %s\n", sufr_hip_last_error(nullptr)); exit(1); }
     sufr_hip_index* ix = nullptr;
-    std::string bytes;
-    std::vector<uint64_t> off(queries.size() + 1, 0), lo(queries.size(), 0), hi(queries.size(), 0);
-    for (size_t i = 0; i < queries.size(); i++) { bytes += queries[i]; off[i + 1] = bytes.size(); }
     if (sufr_hip_index_load(ctx, f, &ix) != 0 ||
         sufr_hip_search_batch(ctx, ix, (const uint8_t*)bytes.data(), off.data(), queries.size(), a.has_mql, a.mql, lo.data(), hi.data()) != 0) {
         fprintf(stderr, "Error: %s\n", sufr_hip_last_error(ctx));
@@ -381,9 +381,10 @@ int cmd_summarize(const QueryArgs& a)
 }
 
 // arguments of the query sub-commands (clap definitions of lib.rs:129-271)
-int run_query(const std::string& cmd, int argc, char** argv, int first)
+int run_query(const std::string& cmd, int argc, char** argv, int first, int threads)
 {
     QueryArgs a;
+    a.threads = threads;
     std::vector<std::string> pos;
     auto need = [&](int& i, const char* opt) -> const char* {
         if (i + 1 >= argc) { fprintf(stderr, "error: a value is required for '%s'\n", opt); exit(2); }
@@ -438,6 +439,7 @@ int main(int argc, char** argv)
     std::vector<int> devices;
     uint64_t window = 0, margin = 0;
     bool have_cmd = false, have_output = false, have_mask = false;
+    int threads = 0;
     sufr_create_args a;
     memset(&a, 0, sizeof a);
     a.num_partitions = 16;
@@ -450,7 +452,7 @@ int main(int argc, char** argv)
     for (int i = 1; i < argc; i++) {
         std::string s = argv[i];
         if (s == "-h" || s == "--help") return usage(stdout);
-        else if (s == "-t" || s == "--threads") (void)need(i, "--threads");
+        else if (s == "-t" || s == "--threads") threads = atoi(need(i, "--threads"));
         else if (s == "-l" || s == "--log") {
             std::string v = need(i, "--log");
             if (v == "info") log.level = 1; else if (v == "debug") log.level = 2;
@@ -473,11 +475,11 @@ int main(int argc, char** argv)
             }
         }
         else if (!have_cmd && (s == "create" || s == "cr")) have_cmd = true;
-        else if (!have_cmd && (s == "count" || s == "co")) return run_query("count", argc, argv, i + 1);
-        else if (!have_cmd && (s == "locate" || s == "lo")) return run_query("locate", argc, argv, i + 1);
-        else if (!have_cmd && (s == "extract" || s == "ex")) return run_query("extract", argc, argv, i + 1);
-        else if (!have_cmd && (s == "list" || s == "ls")) return run_query("list", argc, argv, i + 1);
-        else if (!have_cmd && (s == "summarize" || s == "su")) return run_query("summarize", argc, argv, i + 1);
+        else if (!have_cmd && (s == "count" || s == "co")) return run_query("count", argc, argv, i + 1, threads);
+        else if (!have_cmd && (s == "locate" || s == "lo")) return run_query("locate", argc, argv, i + 1, threads);
+        else if (!have_cmd && (s == "extract" || s == "ex")) return run_query("extract", argc, argv, i + 1, threads);
+        else if (!have_cmd && (s == "list" || s == "ls")) return run_query("list", argc, argv, i + 1, threads);
+        else if (!have_cmd && (s == "summarize" || s == "su")) return run_query("summarize", argc, argv, i + 1, threads);
         else if (!have_cmd) { fprintf(stderr, "error: unrecognized subcommand '%s'\n", s.c_str()); return 2; }
         else if (s == "-n" || s == "--num-partitions") a.num_partitions = strtoull(need(i, "-n"), nullptr, 10);
         else if (s == "-m" || s == "--max-query-len") { a.has_max_query_len = 1; a.max_query_len = strtoull(need(i, "-m"), nullptr, 10); }

@@ -11,7 +11,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sufr_hip.h"
@@ -253,6 +255,33 @@ int sufr_file_search(const sufr_file* f, const uint8_t* q, size_t qlen, int has_
     }
     *rank_lo = first; *rank_hi = last + 1;
     return 1;
+}
+
+int sufr_file_search_batch(const sufr_file* f, const uint8_t* queries, const uint64_t* offsets, uint64_t nq, int has_mql,
+                           uint64_t mql, uint64_t* rank_lo, uint64_t* rank_hi, int threads)
+{
+    if (!f || (nq && (!offsets || !rank_lo || !rank_hi))) return SUFR_HIP_E_INVALID;
+    unsigned T = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (T == 0) T = 1;
+    if (T > nq / 64 + 1) T = (unsigned)(nq / 64 + 1);          // a worker is not worth fewer than 64 queries
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint64_t b = next.fetch_add(256);
+            if (b >= nq) return;
+            const uint64_t e = b + 256 < nq ? b + 256 : nq;
+            for (uint64_t i = b; i < e; i++) {
+                uint64_t lo = 0, hi = 0;
+                const int hit = sufr_file_search(f, queries + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), has_mql, mql, &lo, &hi);
+                rank_lo[i] = hit ? lo : 0; rank_hi[i] = hit ? hi : 0;
+            }
+        }
+    };
+    if (T == 1) { worker(); return 0; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    return 0;
 }
 
 }  // extern "C"

@@ -151,12 +151,21 @@ class SufrFile:
                                      C.byref(lo), C.byref(hi))
         return (lo.value, hi.value) if hit else None
 
+    def search_batch(self, queries: Sequence, max_query_len: Optional[int] = None, threads: int = 0):
+        """rank_lo, rank_hi (uint64 arrays, lo == hi == 0: not found) for a batch, `threads` host workers (0: one per core):
+        the rayon loop of SufrFile::count / locate (sufr_file.rs:760-800)."""
+        qb, off = pack_queries(queries)
+        lo = np.zeros(len(off) - 1, dtype=np.uint64)
+        hi = np.zeros(len(off) - 1, dtype=np.uint64)
+        rc = lib().sufr_file_search_batch(self._h, qb.ctypes.data, off.ctypes.data, len(off) - 1, int(max_query_len is not None),
+                                          max_query_len or 0, lo.ctypes.data, hi.ctypes.data, threads)
+        if rc != 0:
+            raise SufrHipError(rc, "sufr_file_search_batch failed")
+        return lo, hi
+
     def count(self, queries: Sequence, max_query_len: Optional[int] = None, low_memory: bool = False) -> List[CountResult]:
-        out = []
-        for i, q in enumerate(queries):
-            r = self.search(q, max_query_len)
-            out.append(CountResult(i, q if isinstance(q, str) else bytes(q).decode("latin-1"), r[1] - r[0] if r else 0))
-        return out
+        lo, hi = self.search_batch(queries, max_query_len)
+        return [CountResult(i, q if isinstance(q, str) else bytes(q).decode("latin-1"), int(hi[i] - lo[i])) for i, q in enumerate(queries)]
 
     def _sequence_of(self, suffix: int) -> int:
         return lib().sufr_file_sequence_of(self._h, suffix)

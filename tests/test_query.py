@@ -319,6 +319,21 @@ def test_search_equals_witness_on_truncated_and_masked_builds(oracle, tmp_path, 
     assert check_against_witness(f, random_queries(rng, f, 60, max_len), mql) > 0
 
 
+@pytest.mark.parametrize("threads", [1, 3, 0])
+def test_threaded_batch_equals_single_searches(threads):
+    f = SufrFile(LONG)
+    rng = np.random.default_rng(8)
+    queries = random_queries(rng, f, 3000, 14)
+    for mql in (None, 5):
+        lo, hi = f.search_batch(queries, mql, threads=threads)
+        for i, q in enumerate(queries):
+            r = f.search(q, mql)
+            assert (int(lo[i]), int(hi[i])) == (r if r else (0, 0))
+    lo, hi = f.search_batch([], threads=threads)
+    assert lo.size == 0
+    assert run("-t", 2, "count", SUFR1, "AC", "X", "GT").stdout == "AC 2\nX 0\nGT 2\n"
+
+
 def test_empty_query_matches_every_suffix():
     f = SufrFile(SUFR1)
     assert f.search(b"") == (0, 9)
