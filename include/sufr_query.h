@@ -95,6 +95,16 @@ int  sufr_hip_search_batch_device(sufr_hip_ctx *ctx, const sufr_hip_index *ix, c
                                   uint64_t num_queries, int has_max_query_len, uint64_t max_query_len, void *d_rank_lo,
                                   void *d_rank_hi);
 
+/* locate: the positions behind the rank ranges of a batch (SufrFile::locate, sufr_file.rs:1110-1175, without the
+ * sequence names: those are a host lookup per position, sufr_file_sequence_of).  For query i the suffixes
+ * SA[lo_i .. min(hi_i, lo_i + max_hits)) in rank order (max_hits 0: all) land in d_positions[d_offsets[i] .. d_offsets[i+1]);
+ * d_offsets holds num_queries + 1 u64, d_positions up to `cap` u32.  *total_out = d_offsets[num_queries] even when it
+ * exceeds cap (the call then returns SUFR_HIP_E_CAPACITY and gathers nothing).  Enqueued on the context's stream after
+ * one synchronisation for the total. */
+int  sufr_hip_locate_batch_device(sufr_hip_ctx *ctx, const sufr_hip_index *ix, const void *d_rank_lo, const void *d_rank_hi,
+                                  uint64_t num_queries, uint64_t max_hits, void *d_offsets, void *d_positions, uint64_t cap,
+                                  uint64_t *total_out);
+
 #ifdef __cplusplus
 }
 #endif

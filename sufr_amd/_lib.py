@@ -77,7 +77,7 @@ QUERY_EXPORTS = [
     "sufr_file_suffix_array", "sufr_file_lcp_array", "sufr_file_suffix", "sufr_file_lcp", "sufr_file_sequence_start",
     "sufr_file_sequence_name", "sufr_file_sequence_of", "sufr_file_search", "sufr_file_search_batch",
     "sufr_hip_index_load", "sufr_hip_index_wrap", "sufr_hip_index_free", "sufr_hip_search_batch",
-    "sufr_hip_search_batch_device",
+    "sufr_hip_search_batch_device", "sufr_hip_locate_batch_device",
 ]
 
 
@@ -180,6 +180,8 @@ def lib() -> C.CDLL:
     L.sufr_hip_search_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]; L.sufr_hip_search_batch.restype = C.c_int
     L.sufr_hip_search_batch_device.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]
     L.sufr_hip_search_batch_device.restype = C.c_int
+    L.sufr_hip_locate_batch_device.argtypes = [vp, vp, vp, vp, u64, u64, vp, vp, u64, C.POINTER(u64)]
+    L.sufr_hip_locate_batch_device.restype = C.c_int
     _lib = L
     return L
 

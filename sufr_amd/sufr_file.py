@@ -324,6 +324,34 @@ class DeviceIndex:
             self.ctx.synchronize()
         return lo, hi
 
+    def locate_device(self, lo, hi, max_hits: int = 0, capacity: Optional[int] = None):
+        """Positions behind rank ranges that are on the device (torch int64 tensors from search_device): returns
+        (offsets int64[nq + 1], positions int32 holding u32 values); query i owns positions[offsets[i]:offsets[i + 1]],
+        in rank order, at most max_hits of them (0: all)."""
+        import torch
+        nq = lo.numel()
+        off = torch.empty(nq + 1, dtype=torch.int64, device=lo.device)
+        total = C.c_uint64(0)
+        torch.cuda.current_stream(lo.device).synchronize()
+        if capacity is None:                                   # size the output from the counts
+            cnt = hi - lo
+            capacity = int((cnt.clamp(max=max_hits) if max_hits else cnt).sum())
+        pos = torch.empty(max(capacity, 1), dtype=torch.int32, device=lo.device)
+        self.ctx.check(lib().sufr_hip_locate_batch_device(self.ctx.handle, self._h, lo.data_ptr(), hi.data_ptr(), nq, max_hits,
+                                                         off.data_ptr(), pos.data_ptr(), capacity, C.byref(total)))
+        self.ctx.synchronize()
+        return off, pos[:total.value]
+
+    def locate(self, queries: Sequence, max_query_len: Optional[int] = None, max_hits: int = 0) -> List[np.ndarray]:
+        """Text positions of every query's matches in rank order (uint32 arrays), searched and gathered on the device."""
+        import torch
+        qb, off = pack_queries(queries)
+        dev = torch.device("cuda", self.ctx.device)
+        lo, hi = self.search_device(torch.from_numpy(qb).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev), max_query_len)
+        o, p = self.locate_device(lo, hi, max_hits)
+        o = o.cpu().numpy(); p = p.cpu().numpy().view(np.uint32)
+        return [p[o[i]:o[i + 1]] for i in range(len(queries))]
+
     def count(self, queries: Sequence, max_query_len: Optional[int] = None) -> List[CountResult]:
         lo, hi = self.search(queries, max_query_len)
         return [CountResult(i, q if isinstance(q, str) else bytes(q).decode("latin-1"), int(hi[i] - lo[i]))

@@ -184,3 +184,26 @@ def test_cli_extract_on_the_device(case):
     path, queries, opts, lines, err = EXTRACT_CASES[case]
     r = run("extract", path, "--device", 0, *opts, *queries)
     assert r.stdout == "".join(l + "\n" for l in lines) and r.stderr == err
+
+
+@pytest.mark.parametrize("name", ["abba.sufr", "2.sufr", "long_dna_sequence.sufr", "uniprot.sufr", "uniprot-masked.sufr"])
+def test_device_locate_equals_host_locate(ctx, name):
+    """positions gathered on the device = SufrFile::locate's suffixes in rank order (sufr_file.rs:1110-1175)"""
+    f = SufrFile(EXP / name)
+    ix = DeviceIndex.load(ctx, f)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    queries = random_queries(rng, f, 2000, len(f.seed_mask) if f.seed_mask else 10)
+    want = f.locate(queries)
+    got = ix.locate(queries)
+    assert [g.tolist() for g in got] == [[p.suffix for p in w.positions] for w in want]
+    capped = ix.locate(queries, max_hits=3)
+    assert [g.tolist() for g in capped] == [[p.suffix for p in w.positions][:3] for w in want]
+    assert all(g.size == 0 for g in ix.locate([b"\x01\x02"])) and ix.locate([]) == []
+    # room for fewer positions than there are: refused, with the total reported
+    qb, off = pack_queries(queries)
+    lo, hi = ix.search_device(torch.from_numpy(qb).cuda(), torch.from_numpy(off.astype(np.int64)).cuda())
+    total = int((hi - lo).sum())
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        ix.locate_device(lo, hi, capacity=total - 1)
+    assert e.value.code == -5 and str(total) in e.value.message
+    ix.close()
