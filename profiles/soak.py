@@ -1,5 +1,5 @@
 """A soak of the whole library against the CPU checker with fresh seeds:   python profiles/soak.py [minutes] [seed]
-Loops until the time is up over (1) small random texts (tests/test_gpu_parity.py::_fuzz_text) and structured 20 k - 400 k
+A third argument "big" restricts the loop to structured texts of 1 - 6 Mb.  Loops until the time is up over (1) small random texts (tests/test_gpu_parity.py::_fuzz_text) and structured 20 k - 400 k
 texts through the host ABI, (2) the same texts in forced windows, (3) the device search of the result against the host
 search of the written file.  Prints one line per failure and a summary; exit code 1 when anything differed.
 (Test-side tooling: it imports the checker from tests/, like the tests do.)"""
@@ -18,6 +18,7 @@ from test_query import random_queries
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) % 100000
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"          # structured texts of 1 - 6 Mb only
 rng = np.random.default_rng(seed)
 oracle = Oracle()
 ctx = sufr_amd.Context(0)
@@ -27,7 +28,7 @@ cases = {"host": 0, "windows": 0, "search": 0}
 
 
 def structured(rng):
-    n = int(rng.integers(40_000, 300_000))
+    n = int(rng.integers(1_000_000, 6_000_000)) if BIG else int(rng.integers(40_000, 300_000))
     kind = int(rng.integers(0, 8))
     t = acgt[rng.integers(0, 4, n)]
     if kind == 1:
@@ -72,7 +73,7 @@ t_end = time.time() + minutes * 60
 it = 0
 while time.time() < t_end:
     it += 1
-    if it % 3 == 0:
+    if it % 3 == 0 or BIG:
         raw, kind = structured(rng); is_dna = kind != 5
     else:
         raw = _fuzz_text(rng); kind = -1; is_dna = bool(rng.random() < 0.6)
@@ -89,6 +90,8 @@ while time.time() < t_end:
     except RuntimeError:                    # inputs the reference itself cannot build (pivot hazards): the naive witness
         if norm.size > 20_000:
             continue
+    if BIG and kind in (2, 4) and amb:     # (megabase texts with planted runs and --allow-ambiguity: minutes in the CPU checker)
+        continue
         want_sa, want_lcp = naive_sa_lcp(norm, is_dna, amb)
     want_sa = want_sa.astype(np.uint64); want_lcp = want_lcp.astype(np.uint64)
     # (1) host ABI, one window
