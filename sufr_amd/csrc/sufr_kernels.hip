@@ -216,14 +216,25 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     // per-thread symbol counts: 4-bit lanes per half of the 16 bytes (<= 8 each), widened to 16-bit lanes
     uint64_t acc_even = 0, acc_odd = 0;      // codes 0,2,4,6 / 1,3,5,7; code 0 = bytes outside the set
+    // the 16 bytes of the next tile are fetched while this one is worked on: with two barriers per 4 KB tile a
+    // workgroup otherwise waits out a full memory latency per tile
+    uint4 w_next = make_uint4(0, 0, 0, 0);
+    {
+        const uint64_t q0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
+        if (blockIdx.x < ntiles && q0 + 16 <= n) w_next = *reinterpret_cast<const uint4*>(in + q0);
+    }
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t p0 = tile * TILE + (uint64_t)threadIdx.x * 16;
         uint32_t by[17];
         if (threadIdx.x == 0) { s_min = 0xffffffffu; s_any[0] = 0; s_any[1] = 0; }
         uint32_t vh = 0, vl = 0;             // codes of positions 0..7 / 8..15, 3 bits each, first highest
         uint32_t na = 0, nb = 0;             // nibble counters of the two halves
+        const uint4 w = w_next;
+        {
+            const uint64_t q0 = (tile + gridDim.x) * TILE + (uint64_t)threadIdx.x * 16;
+            if (tile + gridDim.x < ntiles && q0 + 16 <= n) w_next = *reinterpret_cast<const uint4*>(in + q0);
+        }
         if (p0 + 16 <= n) {
-            uint4 w = *reinterpret_cast<const uint4*>(in + p0);
             uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
