@@ -162,3 +162,15 @@ def test_text_beyond_32_bits():
     db.close()
     del x, sa, lcp
     torch.cuda.empty_cache()
+
+
+def test_cli_refuses_masked_builds_in_windows_before_building(tmp_path):
+    fa = GOLDEN / "inputs" / "long_dna_sequence.fa"
+    for extra in (["-m", "8"], ["-s", "1101"]):
+        r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(tmp_path / "x.sufr"), "--window", "4096", *extra],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "one 32-bit window" in r.stderr
+        assert not (tmp_path / "x.sufr").exists()
+    r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(tmp_path / "y.sufr"), "--window", "4096", "-m", "0"],
+                       capture_output=True, text=True)                                   # Some(0): a plain build
+    assert r.returncode == 0, r.stderr
