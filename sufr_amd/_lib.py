@@ -10,7 +10,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "_build" / "libsufr_hip.so"
 # profiles/*.py may point the binding at the probes build (tuning knobs from SUFR_PROBE_*); the package and the
-# tests always use the plain library, which reads no environment besides SUFR_HIP_DEBUG
+# tests always use the plain library, which reads no environment besides SUFR_HIP_DEBUG and SUFR_SERIAL_READER
 if os.environ.get("SUFR_AMD_PROBES_LIB"):
     LIB_PATH = CSRC / "_build" / "libsufr_hip_probes.so"
 CLI_PATH = CSRC / "_build" / "sufr"

@@ -337,7 +337,9 @@ int stream_sections(int device, int fd, const std::vector<Section>& secs)
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
     unsigned W = host_threads(12);
-    if (const char* e = getenv("SUFR_WRITE_THREADS")) if (atoi(e) > 0) W = (unsigned)atoi(e);
+#ifdef SUFR_HIP_PROBES
+    if (const char* e = getenv("SUFR_PROBE_WRITE_THREADS")) if (atoi(e) > 0) W = (unsigned)atoi(e);
+#endif
     if (W > pieces.size()) W = (unsigned)pieces.size();
     auto worker = [&]() {
         void* pin = nullptr;
