@@ -150,7 +150,12 @@ def test_text_beyond_32_bits():
     db = sufr_amd.DeviceBuilder(0)
     with pytest.raises(sufr_amd.SufrHipError):                # the u32 entry point cannot hold these positions
         db.sort(x[:4_300_000_000], is_dna=True)
-    sa, lcp = db.sort(x, is_dna=True, index_width=8)
+    try:
+        sa, lcp = db.sort(x, is_dna=True, index_width=8)
+    except (sufr_amd.SufrHipError, torch.OutOfMemoryError) as e:      # ~200 GB of HBM: a box that cannot spare it skips, loudly
+        if isinstance(e, sufr_amd.SufrHipError) and e.code != -4:
+            raise
+        pytest.skip(f"not enough free HBM for the 4.4e9-byte build: {e}")
     st = db.stats
     assert sa.dtype == torch.int64 and st.text_len == n
     count = verify.check_permutation(x, sa, is_dna=True, raw_is_normalised=True)
