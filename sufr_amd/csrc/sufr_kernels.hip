@@ -169,11 +169,30 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_normalize_pack_dna: the same text map and run-end tables, specialised for the alphabet a DNA build
-// almost always has after normalisation: {'$', '%', 'A', 'C', 'G', 'N', 'T'}.  With the code table fixed in
-// advance (codes 1..7 in byte order, 3 bits) the bit-packed code stream can be written in this very pass
-// and the byte histogram shrinks to eight counters kept in registers; counts[8] counts bytes outside the set
-// -- if it is not zero the host falls back to k_normalize_bytehist and the general code table.
+// k_text_pass_dna: THE one pass over the raw text of a DNA build (replaces the text map of SufrBuilder::new,
+// sufr_builder.rs:144-160, and everything the pivot selection 771-809 needed to know about the text).
+// Specialised for the alphabet a DNA build almost always has after normalisation, {'$', '%', 'A', 'C', 'G', 'N',
+// 'T'}: with the code table fixed in advance (codes 1..7 in byte order, 3 bits; 0 = past the end) one read of the
+// text yields
+//   * the normalised text (what the .sufr file stores),
+//   * the bit-packed code stream (3/8 byte per base) the partition kernel and the run keys read,
+//   * the run-end tables (RunTable of sufr_runkey.h: bitmap, first run end and summary word per 4 KB tile),
+//   * the eight symbol counts (counts[8] = bytes outside the set: the host then falls back to
+//     k_normalize_bytehist and the general code table),
+//   * the histogram of the first DIGIT (5 characters, 15 bits, raw values) of every suffix start, one row per
+//     group of workgroups (group = blockIdx % ngroups, the same chunk -> group map as k_msd_part_text: the
+//     write cursors of the partition kernel come from these rows), and
+//   * the set of 5-mers that occur at ANY position (presence bits; suffix starts are in the histogram): the
+//     dense digit numbering of all MSD levels.
+// Round 2 read the text three times for this (normalise + pack, presence, first-digit histogram).
+//
+// No workgroup barrier inside the loop: a wave owns a 4 KB tile (four sub-blocks of 64 lanes x 16 bytes, all
+// four loads in flight, the next tile's fetched before this one is worked on), takes the four characters after a
+// lane's 16 from the next lane (whole-wave DPP shift; the last lane from the next sub-block, the last
+// sub-block's from memory) and stages its 384 packed bytes per sub-block through a wave-private piece of LDS.
+// The 2^15 raw histogram counters are 128 KB of LDS: one 1024-thread workgroup per CU, 16 autonomous waves.
+// Equal consecutive 5-mers of a lane (homopolymer runs: N runs are half of a soft-masked genome) are counted
+// in a register and added once: an LDS atomic that 64 lanes aim at one counter is serialised.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t dna_fixed_code(uint32_t b)
 {
@@ -188,138 +207,217 @@ __device__ __forceinline__ uint32_t dna_fixed_code(uint32_t b)
     return c;
 }
 
-__global__ void __launch_bounds__(256)
-k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int normalize,
-                     int ignore_softmask, unsigned long long* __restrict__ counts,
-                     uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
-                     uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed,
-                     uint32_t* __restrict__ top_rows, uint32_t elig_codes, uint32_t sample_stride)
+static constexpr int TP_NT = 1024;                 // threads of k_text_pass_dna
+static constexpr int TP_RAW_BINS = 1 << 15;        // raw values of a 5-character digit of 3-bit codes
+static constexpr size_t TP_LDS = (size_t)TP_RAW_BINS * 4 + (TP_RAW_BINS / 32) * 4 + 256 * 2 + (TP_NT / 64) * 192 * 2 + 9 * 8;
+
+// lane i takes the value of lane i + 1 of its wave (lane 63 keeps its own)
+__device__ __forceinline__ uint32_t wave_next_u32(uint32_t v)
 {
-    // top_rows (sharded builds only): per-workgroup counts of the first four characters of the suffixes
-    // that start in every sample_stride-th tile -- the "pivots chosen on device" of a multi-GPU job only need
-    // proportions (positions 13..15 of a thread's 16 are left out: their 4-mer crosses into the next thread)
-    __shared__ uint32_t s_top[4096];
-    __shared__ uint16_t s_tab[256];          // normalised byte << 8 | fixed code (0 = not in the set)
-    __shared__ uint8_t s_first[256 + 4];
-    __shared__ uint32_t s_min;
-    __shared__ uint32_t s_any[2];
-    __shared__ __align__(16) uint16_t s_pack[256 * 3];
-    __shared__ unsigned long long s_tot[9];
-    {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+__global__ void __launch_bounds__(TP_NT)
+k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int normalize,
+                int ignore_softmask, unsigned long long* __restrict__ counts,
+                uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
+                uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed, uint32_t elig_codes,
+                uint64_t chunk, uint32_t ngroups, uint32_t* __restrict__ rawtab, uint32_t* __restrict__ presbits)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);                                   // TP_RAW_BINS
+    uint32_t* s_pres = s_hist + TP_RAW_BINS;                                                // TP_RAW_BINS / 32
+    uint16_t* s_tab = reinterpret_cast<uint16_t*>(s_pres + TP_RAW_BINS / 32);               // 256: byte << 8 | code
+    uint16_t* s_packall = s_tab + 256;                                                      // 192 per wave
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(s_packall + (TP_NT / 64) * 192);   // 9
+    for (int i = threadIdx.x; i < TP_RAW_BINS; i += TP_NT) s_hist[i] = 0;
+    if (threadIdx.x < TP_RAW_BINS / 32) s_pres[threadIdx.x] = 0;
+    if (threadIdx.x < 256) {
         uint32_t b = threadIdx.x;
         if (normalize && b >= 97u && b <= 122u) b = ignore_softmask ? 78u : (b & 0x5Fu);
         s_tab[threadIdx.x] = (uint16_t)((b << 8) | dna_fixed_code(b));
     }
     if (threadIdx.x < 9) s_tot[threadIdx.x] = 0;
-    if (top_rows) for (int i = threadIdx.x; i < 4096; i += 256) s_top[i] = 0;
     __syncthreads();
-    const uint64_t ntiles = (n + TILE - 1) / TILE;
-    // per-thread symbol counts: 4-bit lanes per half of the 16 bytes (<= 8 each), widened to 16-bit lanes
-    uint64_t acc_even = 0, acc_odd = 0;      // codes 0,2,4,6 / 1,3,5,7; code 0 = bytes outside the set
-    // the 16 bytes of the next tile are fetched while this one is worked on: with two barriers per 4 KB tile a
-    // workgroup otherwise waits out a full memory latency per tile
-    uint4 w_next = make_uint4(0, 0, 0, 0);
-    {
-        const uint64_t q0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
-        if (blockIdx.x < ntiles && q0 + 16 <= n) w_next = *reinterpret_cast<const uint4*>(in + q0);
-    }
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t p0 = tile * TILE + (uint64_t)threadIdx.x * 16;
-        uint32_t by[17];
-        if (threadIdx.x == 0) { s_min = 0xffffffffu; s_any[0] = 0; s_any[1] = 0; }
-        uint32_t vh = 0, vl = 0;             // codes of positions 0..7 / 8..15, 3 bits each, first highest
-        uint32_t na = 0, nb = 0;             // nibble counters of the two halves
-        const uint4 w = w_next;
-        {
-            const uint64_t q0 = (tile + gridDim.x) * TILE + (uint64_t)threadIdx.x * 16;
-            if (tile + gridDim.x < ntiles && q0 + 16 <= n) w_next = *reinterpret_cast<const uint4*>(in + q0);
-        }
-        if (p0 + 16 <= n) {
-            uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t ln = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    constexpr uint32_t NW = TP_NT / 64;
+    uint16_t* s_pack = s_packall + (size_t)wv * 192;
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk, c1 = min(c0 + chunk, n);      // chunk: a multiple of TILE
+    const uint64_t t1 = (c1 + TILE - 1) / TILE;
+    uint64_t acc_even = 0, acc_odd = 0;      // 16-bit lanes: codes 0,2,4,6 / 1,3,5,7; code 0 = bytes outside the set
+    auto fetch = [&](uint64_t tile, uint4 (&w)[4]) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t y = 0;
+        for (int k = 0; k < 4; k++) {
+            const uint64_t p = tile * TILE + (uint64_t)k * 1024 + (uint64_t)ln * 16;
+            w[k] = make_uint4(0, 0, 0, 0);
+            if (p + 16 <= n) w[k] = *reinterpret_cast<const uint4*>(in + p);
+            else if (p < n) {
+                uint32_t q[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 16; e++) if (p + e < n) q[e >> 2] |= (uint32_t)in[p + e] << (8 * (e & 3));
+                w[k] = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+        }
+    };
+    uint4 wn[4];
+    uint64_t tile = c0 / TILE + wv;
+    if (tile < t1) fetch(tile, wn);
+    for (; tile < t1; tile += NW) {
+        uint4 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = wn[k];
+        if (tile + NW < t1) fetch(tile + NW, wn);
+        const uint64_t base = tile * TILE;
+        // text map + codes of a sub-block (sub-block k + 1 is mapped before k is finished: k's last lane needs its
+        // first characters)
+        uint32_t y[4][4];
+        uint64_t V[4];                       // 16 codes, 3 bits each, first highest
+        uint32_t L[4];                       // what the lane before needs: first four codes | first byte << 12
+        auto map_sub = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t ws[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+            const uint64_t p = base + (uint64_t)k * 1024 + (uint64_t)ln * 16;
+            uint32_t vh = 0, vl = 0, na = 0, nb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t yy = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t t = s_tab[(ws[k] >> (8 * j)) & 0xffu];
+                    const uint32_t t = s_tab[(ws[q] >> (8 * j)) & 0xffu];
                     const uint32_t b = t >> 8, c = t & 0xffu;
-                    by[4 * k + j] = b;
-                    y |= b << (8 * j);
-                    if (k < 2) { vh = (vh << 3) | c; na += 1u << (4 * c); }
+                    yy |= b << (8 * j);
+                    if (q < 2) { vh = (vh << 3) | c; na += 1u << (4 * c); }
                     else { vl = (vl << 3) | c; nb += 1u << (4 * c); }
                 }
-                ws[k] = y;
+                y[k][q] = yy;
             }
-            *reinterpret_cast<uint4*>(out + p0) = make_uint4(ws[0], ws[1], ws[2], ws[3]);
-        } else {
+            if (p + 16 <= n) {
+                *reinterpret_cast<uint4*>(out + p) = make_uint4(y[k][0], y[k][1], y[k][2], y[k][3]);
+            } else {
+                // the text ends inside these 16 bytes (or before them): nothing past the end is a character
+                uint32_t m[4] = {0, 0, 0, 0};
+                vh = 0; vl = 0; na = 0; nb = 0;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                by[e] = 0;
-                uint32_t c = 0;
-                if (p0 + e < n) {
-                    const uint32_t t = s_tab[in[p0 + e]];
-                    by[e] = t >> 8; c = t & 0xffu;
-                    out[p0 + e] = (uint8_t)by[e];
-                    if (e < 8) na += 1u << (4 * c); else nb += 1u << (4 * c);
+                for (int e = 0; e < 16; e++) {
+                    uint32_t c = 0;
+                    if (p + e < n) {
+                        const uint32_t t = s_tab[(ws[e >> 2] >> (8 * (e & 3))) & 0xffu];
+                        c = t & 0xffu;
+                        m[e >> 2] |= (t >> 8) << (8 * (e & 3));
+                        out[p + e] = (uint8_t)(t >> 8);
+                        if (e < 8) na += 1u << (4 * c); else nb += 1u << (4 * c);
+                    }
+                    if (e < 8) vh = (vh << 3) | c; else vl = (vl << 3) | c;
                 }
-                if (e < 8) vh = (vh << 3) | c; else vl = (vl << 3) | c;
+#pragma unroll
+                for (int q = 0; q < 4; q++) y[k][q] = m[q];
+            }
+            {
+                const uint32_t ea = na & 0x0f0f0f0fu, oa = (na >> 4) & 0x0f0f0f0fu;     // 8-bit lanes
+                const uint32_t eb = nb & 0x0f0f0f0fu, ob = (nb >> 4) & 0x0f0f0f0fu;
+                const uint32_t e8 = ea + eb, o8 = oa + ob;                               // <= 16 per lane
+                acc_even += (uint64_t)(e8 & 0xffu) | ((uint64_t)((e8 >> 8) & 0xffu) << 16) |
+                            ((uint64_t)((e8 >> 16) & 0xffu) << 32) | ((uint64_t)(e8 >> 24) << 48);
+                acc_odd += (uint64_t)(o8 & 0xffu) | ((uint64_t)((o8 >> 8) & 0xffu) << 16) |
+                           ((uint64_t)((o8 >> 16) & 0xffu) << 32) | ((uint64_t)(o8 >> 24) << 48);
+            }
+            V[k] = ((uint64_t)vh << 24) | (uint64_t)vl;
+            L[k] = (vh >> 12) | ((y[k][0] & 0xffu) << 12);
+        };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+        map_sub(K0{});
+        // the four characters after the tile (its last lane's look-ahead)
+        uint32_t Ltail = 0;
+        if (ln == 63u) {
+            const uint64_t p = base + TILE;
+            uint32_t c4 = 0, b0 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t t = 0;
+                if (p + e < n) t = s_tab[in[p + e]];
+                c4 = (c4 << 3) | (t & 0xffu);
+                if (e == 0) b0 = t >> 8;
+            }
+            Ltail = c4 | (b0 << 12);
+        }
+        uint32_t fe = RUN_NONE;              // first run end of the tile
+        uint64_t anyw = 0;                   // bit j: word j of the tile's run-end bitmap is not zero
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k == 0) map_sub(K1{}); else if (k == 1) map_sub(K2{}); else if (k == 2) map_sub(K3{});
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t Lx = wave_next_u32(L[k]);
+            {
+                const uint32_t nextfirst = k < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L[k < 3 ? k + 1 : 3]) : Ltail;
+                if (ln == 63u) Lx = nextfirst;
+            }
+            const uint32_t n12 = Lx & 0xfffu, nbyte = Lx >> 12;
+            // run ends: position e ends a run iff its byte differs from the next one (the byte after the text is 0)
+            uint32_t ends16 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t nxt = q < 3 ? y[k][q < 3 ? q + 1 : 3] : nbyte;
+                const uint32_t d = y[k][q] ^ ((y[k][q] >> 8) | (nxt << 24));
+                const uint32_t z = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;     // high bit of every non-zero byte
+                ends16 |= (((z >> 7) * 0x10204080u) >> 28) << (4 * q);
+            }
+            {
+                // positions past the end of the text end nothing (their bytes are 0 and so is what follows)
+                uint64_t v = (uint64_t)ends16 << (16 * (ln & 3u));
+                v |= shfl64_xor(v, 1);
+                v |= shfl64_xor(v, 2);
+                const uint64_t bal = __ballot(v != 0ull);
+                if ((ln & 3u) == 0u) run_ends[tile * 64 + (uint32_t)k * 16 + (ln >> 2)] = v;
+                if (bal) {
+                    uint64_t x = bal & 0x1111111111111111ull;                     // one bit per word
+                    x = (x | (x >> 3)) & 0x0303030303030303ull;
+                    x = (x | (x >> 6)) & 0x000f000f000f000full;
+                    x = (x | (x >> 12)) & 0x000000ff000000ffull;
+                    x = (x | (x >> 24)) & 0xffffull;
+                    anyw |= x << (16 * k);
+                    if (fe == RUN_NONE) {
+                        const int q = __builtin_ctzll(bal);                       // a lane of the first word with an end
+                        const uint64_t vq = shfl64(v, q);
+                        fe = (uint32_t)(base + (uint64_t)k * 1024 + (uint64_t)(q >> 2) * 64 + (uint32_t)__builtin_ctzll(vq));
+                    }
+                }
+            }
+            // packed stream: 6 bytes per lane, 384 per sub-block, written as 24 x 16 bytes
+            {
+#pragma unroll
+                for (int h = 0; h < 3; h++) {
+                    const uint32_t hh = (uint32_t)(V[k] >> (16 * (2 - h))) & 0xffffu;
+                    s_pack[ln * 3 + h] = (uint16_t)((hh >> 8) | (hh << 8));       // big-endian byte order
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (ln < 24u) {
+                    const uint4 q = reinterpret_cast<const uint4*>(s_pack)[ln];
+                    reinterpret_cast<uint4*>(packed + tile * (uint64_t)(TILE * 3 / 8) + (uint64_t)k * 384)[ln] = q;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // first digit of every suffix start -> histogram; 5-mers that start no suffix -> presence bits
+            {
+                const uint64_t X = (V[k] << 12) | (uint64_t)n12;                  // 20 codes
+                uint32_t pm = 0xffffffffu, pc = 0;                                // pending 5-mer, its suffix starts
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t mer = (uint32_t)(X >> (45 - 3 * e)) & 0x7fffu;
+                    const uint32_t el = (elig_codes >> (mer >> 12)) & 1u;
+                    if (mer == pm) pc += el;
+                    else {
+                        if (pc) atomicAdd(&s_hist[pm], pc);
+                        else if (pm != 0xffffffffu) atomicOr(&s_pres[pm >> 5], 1u << (pm & 31u));
+                        pm = mer; pc = el;
+                    }
+                }
+                if (pc) atomicAdd(&s_hist[pm], pc);
+                else atomicOr(&s_pres[pm >> 5], 1u << (pm & 31u));
             }
         }
-        {
-            const uint32_t ea = na & 0x0f0f0f0fu, oa = (na >> 4) & 0x0f0f0f0fu;     // 8-bit lanes
-            const uint32_t eb = nb & 0x0f0f0f0fu, ob = (nb >> 4) & 0x0f0f0f0fu;
-            const uint32_t e8 = ea + eb, o8 = oa + ob;                               // <= 16 per lane
-            acc_even += (uint64_t)(e8 & 0xffu) | ((uint64_t)((e8 >> 8) & 0xffu) << 16) |
-                        ((uint64_t)((e8 >> 16) & 0xffu) << 32) | ((uint64_t)(e8 >> 24) << 48);
-            acc_odd += (uint64_t)(o8 & 0xffu) | ((uint64_t)((o8 >> 8) & 0xffu) << 16) |
-                       ((uint64_t)((o8 >> 16) & 0xffu) << 32) | ((uint64_t)(o8 >> 24) << 48);
-        }
-        const uint64_t V = ((uint64_t)vh << 24) | (uint64_t)vl;                      // 16 codes, 48 bits
-        if (top_rows && tile % sample_stride == 0) {
-#pragma unroll
-            for (int e = 0; e <= 12; e++) {
-                const uint32_t mer = (uint32_t)(V >> (36 - 3 * e)) & 0xfffu;
-                if ((elig_codes >> (mer >> 9)) & 1u) atomicAdd(&s_top[mer], 1u);
-            }
-        }
-        s_first[threadIdx.x] = (uint8_t)by[0];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t hh = (uint32_t)(V >> (16 * (2 - k))) & 0xffffu;
-            s_pack[threadIdx.x * 3 + k] = (uint16_t)((hh >> 8) | (hh << 8));   // big-endian byte order
-        }
-        __syncthreads();
-        if (threadIdx.x < 255) by[16] = s_first[threadIdx.x + 1];
-        else by[16] = (p0 + 16 < n) ? (uint32_t)(s_tab[in[p0 + 16]] >> 8) : 0u;
-        {
-            uint4* dst = reinterpret_cast<uint4*>(packed + tile * (uint64_t)(TILE * 3 / 8));
-            const uint4* src = reinterpret_cast<const uint4*>(s_pack);
-            if (threadIdx.x < TILE * 3 / 8 / 16) dst[threadIdx.x] = src[threadIdx.x];
-        }
-        uint32_t best = 0xffffffffu;
-        uint32_t ends16 = 0;
-#pragma unroll
-        for (int e = 15; e >= 0; e--) {
-            uint64_t p = p0 + e;
-            if (p < n && (p == n - 1 || by[e] != by[e + 1])) { best = (uint32_t)p; ends16 |= 1u << e; }
-        }
-        if (best != 0xffffffffu) atomicMin(&s_min, best);
-        {
-            uint64_t v = (uint64_t)ends16 << (16 * (threadIdx.x & 3u));
-            v |= shfl64_xor(v, 1);
-            v |= shfl64_xor(v, 2);
-            if ((threadIdx.x & 3u) == 0) {
-                const uint32_t j = threadIdx.x >> 2;
-                run_ends[tile * 64 + j] = v;
-                if (v) atomicOr(&s_any[j >> 5], 1u << (j & 31u));
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            first_end[tile] = s_min;
-            tile_any[tile] = (uint64_t)s_any[0] | ((uint64_t)s_any[1] << 32);
-        }
-        __syncthreads();
+        if (ln == 0u) { first_end[tile] = fe; tile_any[tile] = anyw; }
     }
     // eight symbol counts (code 0 = bytes outside the set): wave reduction, then one atomic per wave
     uint32_t cnt[8];
@@ -333,15 +431,47 @@ k_normalize_pack_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
         uint32_t v = cnt[c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-        if (lane_id() == 0 && v) atomicAdd(&s_tot[c == 0 ? 8 : c], (unsigned long long)v);
+        if (ln == 0 && v) atomicAdd(&s_tot[c == 0 ? 8 : c], (unsigned long long)v);
     }
     __syncthreads();
     if (threadIdx.x < 9 && s_tot[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_tot[threadIdx.x]);
-    // with gridDim a multiple of the stride only every sample_stride-th workgroup ever meets a sampled tile
-    // (tile = blockIdx + k * gridDim): those workgroups own the rows
-    if (top_rows && blockIdx.x % sample_stride == 0)
-        for (int i = threadIdx.x; i < 4096; i += 256)
-            top_rows[(size_t)(blockIdx.x / sample_stride) * 4096 + i] = s_top[i];
+    uint32_t* row = rawtab + (size_t)(blockIdx.x % ngroups) * TP_RAW_BINS;
+    for (int i = threadIdx.x; i < TP_RAW_BINS; i += TP_NT) {
+        const uint32_t c = s_hist[i];
+        if (c) atomicAdd(&row[i], c);
+    }
+    if (threadIdx.x < TP_RAW_BINS / 32) {
+        const uint32_t b = s_pres[threadIdx.x];
+        if (b) atomicOr(&presbits[threadIdx.x], b);
+    }
+}
+
+// rawtot[v] = suffix starts whose first digit is v (all groups); flags[v] = 1 iff the 5-mer v occurs anywhere
+__global__ void __launch_bounds__(256)
+k_fold_raw(const uint32_t* __restrict__ rawtab, uint32_t ngroups, const uint32_t* __restrict__ presbits,
+           uint32_t* __restrict__ rawtot, uint32_t* __restrict__ flags)
+{
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= (uint32_t)TP_RAW_BINS) return;
+    uint32_t t = 0;
+    for (uint32_t g = 0; g < ngroups; g++) t += rawtab[(size_t)g * TP_RAW_BINS + v];
+    rawtot[v] = t;
+    flags[v] = (t || ((presbits[v >> 5] >> (v & 31u)) & 1u)) ? 1u : 0u;
+}
+
+// grouptab[g][d] = suffix starts of group g whose first digit has dense value d: the raw values
+// [vals[d] << fold, (vals[d] + 1) << fold) (fold > 0: a digit of fewer characters than the histogram's five)
+__global__ void __launch_bounds__(256)
+k_dense_grouptab(const uint32_t* __restrict__ rawtab, uint32_t ngroups, const uint32_t* __restrict__ vals,
+                 uint32_t NB, int fold, uint32_t* __restrict__ grouptab)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ngroups * NB) return;
+    const uint32_t g = i / NB, d = i % NB;
+    const uint32_t* row = rawtab + (size_t)g * TP_RAW_BINS + ((size_t)vals[d] << fold);
+    uint32_t t = 0;
+    for (uint32_t j = 0; j < (1u << fold); j++) t += row[j];
+    grouptab[i] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,57 +789,6 @@ k_digit_presence(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS)
         if (s_flag[i]) flags[i] = 1u;
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_presence_hist_packed: k_digit_presence for a text whose packed code stream already exists, fused with
-// the pass-0 histogram (of the suffixes whose raw top digit lies in [top_lo, top_hi): the shard filter).  The dense digit remap is not known yet (it is derived from
-// the flags this kernel produces), so the histogram is taken on raw digit values, one row of raw_bins
-// counters per workgroup; k_densify_table folds the rows into the dense [workgroup][bin] table afterwards.
-// ---------------------------------------------------------------------------------------------
-template <int B>
-__global__ void __launch_bounds__(THREADS)
-k_presence_hist_packed(uint64_t n, KeyParams kp, int shift, uint64_t chunk, uint32_t top_lo, uint32_t top_hi,
-                       uint32_t* __restrict__ flags, uint32_t* __restrict__ table_raw)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);                  // raw_bins (only with table_raw)
-    uint8_t* s_flag = smem + (table_raw ? (size_t)kp.raw_bins * 4 : 0);   // raw_bins
-    const uint32_t raw_mask = kp.raw_bins - 1;
-    for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS) { s_flag[i] = 0; if (table_raw) s_hist[i] = 0; }
-    __syncthreads();
-    const uint64_t c0 = (uint64_t)blockIdx.x * chunk;
-    const uint64_t c1 = min(c0 + chunk, n);
-    for (uint64_t tile0 = c0; tile0 < c1; tile0 += TILE) {
-        TileKeys tk;
-        build_keys_packed_t<B, EPT>(kp.packed, tile0 + (uint64_t)threadIdx.x * EPT, kp.elig_codes, tk.key, tk.elig);
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const uint32_t top = (uint32_t)(tk.key[e] >> kp.top_shift);
-            s_flag[top] = 1;                                              // positions past n give digit 0
-            if (table_raw && (tk.elig & (1u << e)) && top >= top_lo && top < top_hi)   // raw range of the shard
-                atomicAdd(&s_hist[(uint32_t)(tk.key[e] >> shift) & raw_mask], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kp.raw_bins; i += THREADS) {
-        if (s_flag[i]) flags[i] = 1u;
-        if (table_raw) table_raw[(size_t)blockIdx.x * kp.raw_bins + i] = s_hist[i];
-    }
-}
-
-// table[w][remap[v]] = table_raw[w][v] for every digit value v that occurs (table zeroed beforehand; the
-// remap is injective on the values that occur, all others have count 0)
-__global__ void __launch_bounds__(256)
-k_densify_table(const uint32_t* __restrict__ table_raw, const uint16_t* __restrict__ remap, uint32_t nwg,
-                uint32_t raw_bins, uint32_t nbins, uint32_t* __restrict__ table)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (uint64_t)nwg * raw_bins) return;
-    const uint32_t c = table_raw[i];
-    if (!c) return;
-    const uint32_t w = (uint32_t)(i / raw_bins), v = (uint32_t)(i % raw_bins);
-    table[(size_t)w * nbins + remap[v]] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
