@@ -1,7 +1,9 @@
 #!/bin/bash
-# Kernel-time table only (no counters): bash profiles/quick.sh <tag> [human|elegans|ecoli]
+# Kernel-time table only (no counters): bash profiles/quick.sh <tag> [human|elegans|ecoli] ["SUFR_PROBE_X=.. .."]
+# (a third argument runs the probes build with those knobs)
 set -u
-TAG=${1:-q}; WL=${2:-human}
+TAG=${1:-q}; WL=${2:-human}; KNOBS=${3:-}
+if [ -n "$KNOBS" ]; then export SUFR_AMD_PROBES_LIB=1; for kv in $KNOBS; do export "$kv"; done; fi
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/quick_$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

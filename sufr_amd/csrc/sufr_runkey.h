@@ -220,4 +220,26 @@ SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
 }
 
 
+// Counting digit of the leaf sort for keys of the fixed 3-bit DNA codes (0 pad, 1 '$', 2 '%', 3 A, 4 C, 5 G, 6 N,
+// 7 T): the six characters in the low 18 bits of t (first character highest) go to 2 bits each, A C G T -> 0 1 2 3.
+// The other codes start no interval of their own: pad '$' '%' sit at the left end of A's, N at the left end of
+// T's, and NOTHING AFTER such a character counts (zeros) -- a point, not an interval.  That keeps the digest
+// monotone: t < t'  =>  digest(t) <= digest(t'), which is all the leaf sort needs of it (merging two characters
+// into one value without cutting the tail would not be: "GT" < "NA" but 2 3 > 2 0).
+SUFR_HD uint32_t dna3_digest12(uint32_t t)
+{
+    const uint32_t Q = 0x24924u;                                  // bit 2 of every 3-bit field
+    const uint32_t B2 = t & Q, B1 = (t << 1) & Q, B0 = (t << 2) & Q;
+    const uint32_t M1 = B2 & (B1 | B0);                           // codes 5 6 7
+    const uint32_t M0 = B2 & (B1 | (B0 ^ Q));                     // codes 4 6 7
+    const uint32_t ST = (~B2 & ~(B1 & B0) & Q) | (B2 & B1 & (B0 ^ Q));   // codes 0 1 2 and 6: the tail is cut
+    uint32_t W = (M1 | (M0 >> 1)) >> 1;                           // character i: value in bits [3i + 1 : 3i]
+    uint32_t S = ST >> 2;                                         // character i: cut flag in bit 3i
+    S |= S >> 3; S |= S >> 6; S |= S >> 12;                       // every character at or after a cut
+    const uint32_t Z = S >> 3;                                    // strictly after
+    W &= ~(Z | (Z << 1));
+    const uint32_t P = (W & 0x030c3u) | ((W >> 1) & 0x0c30cu);    // pairs of characters: 4 bits at 0, 6, 12
+    return (P & 0xfu) | ((P >> 2) & 0xf0u) | ((P >> 4) & 0xf00u);
+}
+
 }  // namespace sufr

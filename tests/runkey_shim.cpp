@@ -77,4 +77,9 @@ void shim_pack_codes(const uint8_t* text, uint64_t n, const uint16_t* lut, int b
 uint32_t shim_run_key_common(uint64_t a, uint64_t b, int bits) { return sufr::run_key_common(a, b, bits); }
 uint32_t shim_run_key_advance(uint64_t k, int sorted_bits, int bits) { return sufr::run_key_advance(k, sorted_bits, bits); }
 uint32_t shim_plain_key_common(uint64_t a, uint64_t b, int bits, int K) { return sufr::plain_key_common(a, b, bits, K); }
+// dna3_digest12 over all 2^18 six-character strings: out[t]
+void shim_dna3_digest_all(uint32_t* out)
+{
+    for (uint32_t t = 0; t < (1u << 18); t++) out[t] = sufr::dna3_digest12(t);
+}
 }

@@ -140,3 +140,27 @@ def test_run_len_at_matches_bytewise_runs(shim):
         for q in qs.tolist():
             got = shim.shim_run_len_at(n, q, tab.ctypes.data)
             assert got == int(want[q]), (q, got, int(want[q]))
+
+
+def test_dna3_digest_is_monotone_and_spreads_acgt(shim):
+    """The counting digit of the leaf sort for 3-bit DNA keys (k_leaf_sort<.., DNA3>): monotone over all 2^18
+    six-character strings (records are bucketed by it and only ranked by whole keys INSIDE a bucket), 2 bits per
+    A / C / G / T, and nothing after a pad / '$' / '%' / N counts."""
+    shim.shim_dna3_digest_all.argtypes = [C.c_void_p]
+    d = np.zeros(1 << 18, dtype=np.uint32)
+    shim.shim_dna3_digest_all(d.ctypes.data)
+    assert (np.diff(d.astype(np.int64)) >= 0).all()
+    t = np.arange(1 << 18, dtype=np.uint32)
+    ref = np.zeros_like(t)
+    cut = np.zeros(t.shape, dtype=bool)
+    for i in range(5, -1, -1):
+        c = (t >> (3 * i)) & 7
+        m = np.select([c < 4, c == 4, c == 5], [0, 1, 2], 3).astype(np.uint32)
+        ref = (ref << 2) | np.where(cut, 0, m).astype(np.uint32)
+        cut |= (c < 3) | (c == 6)
+    assert np.array_equal(d, ref)
+    acgt = np.array([3, 4, 5, 7])
+    idx = np.zeros(4 ** 6, dtype=np.uint32)
+    for i in range(6):
+        idx = (idx << 3) | acgt[(np.arange(4 ** 6) >> (2 * (5 - i))) & 3].astype(np.uint32)
+    assert np.array_equal(d[idx], np.arange(4 ** 6, dtype=np.uint32))       # a bijection on ACGT^6
