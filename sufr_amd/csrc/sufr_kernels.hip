@@ -183,7 +183,9 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 //     group of workgroups (group = blockIdx % ngroups, the same chunk -> group map as k_msd_part_text: the
 //     write cursors of the partition kernel come from these rows), and
 //   * the set of 5-mers that occur at ANY position (presence bits; suffix starts are in the histogram): the
-//     dense digit numbering of all MSD levels.
+//     dense digit numbering of all MSD levels, and
+//   * the suffix-start bitmap (one bit per position: eligibility, sufr_builder.rs:446-449), the work list of
+//     k_msd_part_text.
 // Round 2 read the text three times for this (normalise + pack, presence, first-digit histogram).
 //
 // No workgroup barrier inside the loop: a wave owns a 4 KB tile (four sub-blocks of 64 lanes x 16 bytes, all
@@ -222,7 +224,8 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
                 int ignore_softmask, unsigned long long* __restrict__ counts,
                 uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
                 uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed, uint32_t elig_codes,
-                uint64_t chunk, uint32_t ngroups, uint32_t* __restrict__ rawtab, uint32_t* __restrict__ presbits)
+                uint64_t chunk, uint32_t ngroups, uint32_t* __restrict__ rawtab, uint32_t* __restrict__ presbits,
+                uint64_t* __restrict__ startbits)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);                                   // TP_RAW_BINS
@@ -402,10 +405,12 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
             {
                 const uint64_t X = (V[k] << 12) | (uint64_t)n12;                  // 20 codes
                 uint32_t pm = 0xffffffffu, pc = 0;                                // pending 5-mer, its suffix starts
+                uint32_t em = 0;                                                  // bit e: position e starts a suffix
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const uint32_t mer = (uint32_t)(X >> (45 - 3 * e)) & 0x7fffu;
                     const uint32_t el = (elig_codes >> (mer >> 12)) & 1u;
+                    em |= el << e;
                     if (mer == pm) pc += el;
                     else {
                         if (pc) atomicAdd(&s_hist[pm], pc);
@@ -415,6 +420,11 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
                 }
                 if (pc) atomicAdd(&s_hist[pm], pc);
                 else atomicOr(&s_pres[pm >> 5], 1u << (pm & 31u));
+                // suffix-start bitmap (the partition kernel's work list): four lanes share a 64-bit word
+                uint64_t sv = (uint64_t)em << (16 * (ln & 3u));
+                sv |= shfl64_xor(sv, 1);
+                sv |= shfl64_xor(sv, 2);
+                if ((ln & 3u) == 0u) startbits[tile * 64 + (uint32_t)k * 16 + (ln >> 2)] = sv;
             }
         }
         if (ln == 0u) { first_end[tile] = fe; tile_any[tile] = anyw; }
