@@ -313,15 +313,22 @@ def main():
                                out_lcp=out_lcp, num_partitions=partitions, **flags)
         s_local = builder.num_suffixes
         if world > 1:
-            # the only exchange of the path: {first, last, count} per rank, then the boundary-LCP stitch
-            first = int(sa[0].item()) & 0xFFFFFFFF if s_local else 0
-            last = int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0
-            bounds = shards.exchange_boundaries(first, last, s_local, dev if args.backend == "nccl" else "cpu", dist)
-            k = shards.stitched_first_lcp(
-                bounds, rank, lambda st, ln: sufr_amd.normalize(text[st:st + ln].cpu().numpy(), soft), n)
-            if k is not None:
-                lcp[0] = k
-            totals["s_total"] = sum(b[2] for b in bounds)
+            # the only exchange of the path: {first, last, count} per rank (24 bytes, assembled on the device and
+            # gathered into device memory), then the boundary-LCP stitch as a kernel on this rank's text
+            if args.backend == "nccl":
+                bounds = shards.gather_boundaries_device(sa, s_local, dist)
+                shards.stitch_device(builder.ctx, n, bounds, rank, lcp)
+                totals["bounds"] = bounds               # (read once, after the timed region)
+            else:
+                # gloo smoke test (CPU tensors): the host form of the same exchange
+                first = int(sa[0].item()) & 0xFFFFFFFF if s_local else 0
+                last = int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0
+                bl = shards.exchange_boundaries(first, last, s_local, "cpu", dist)
+                k = shards.stitched_first_lcp(
+                    bl, rank, lambda st, ln: sufr_amd.normalize(text[st:st + ln].cpu().numpy(), soft), n)
+                if k is not None:
+                    lcp[0] = k
+                totals["bounds"] = torch.tensor(bl, dtype=torch.int64)
         else:
             totals["s_total"] = s_local
         return sa, lcp
@@ -378,6 +385,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = allmax(dt)
 
+    if world > 1:
+        totals["s_total"] = int(totals["bounds"][:, 2].sum().item())      # one read-back, outside the timed region
     s_total = totals["s_total"]
     verified = None
     search = None

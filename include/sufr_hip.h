@@ -140,6 +140,15 @@ int sufr_hip_sort_device_u64(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, 
                              void *d_sa, void *d_lcp, uint64_t cap,
                              uint64_t *num_suffixes_out, sufr_hip_stats *stats);
 
+/* Boundary fix of a shard that stays in HBM (one shard per GPU; replaces the LCP write of the partition loop of
+ * SufrBuilder::write, sufr_builder.rs:893-902, for device-resident arrays): d_bounds = [num_shards][3] uint64 in
+ * device memory, {first suffix, last suffix, count} of every shard -- what the ranks all_gather after
+ * sufr_hip_sort_device_u32 (24 bytes per rank).  Sets d_lcp[0] of shard `shard_index` to the exact LCP of its first
+ * suffix with the last suffix of the nearest non-empty shard before it, on the device text of the context's last
+ * build; the pair never visits the host.  Shard 0 and empty shards are left as they are. */
+int sufr_hip_stitch_device_u32(sufr_hip_ctx *ctx, uint64_t n, const uint64_t *d_bounds, uint32_t shard_index,
+                               uint32_t num_shards, void *d_lcp);
+
 /* Host-buffer variants: H2D copy of the text, build, D2H copy of SA and LCP.
  * If norm_text_out != NULL it receives the normalised text (what write() stores in the file). */
 int sufr_hip_build_u32(sufr_hip_ctx *ctx, const uint8_t *text, uint64_t n, uint32_t flags,

@@ -2192,6 +2192,38 @@ k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b,
     }
 }
 
+// The same boundary fix for a shard that stays on the device (N-GPU sort, one shard per rank): bounds[r] =
+// {first suffix, last suffix, count} of every shard (the 24 bytes per rank of the all_gather, still in HBM);
+// LCP[0] of shard `rank` := find_lcp(last suffix of the nearest non-empty shard before it, SA[0], text_len, 0).
+// No host round trip: the pair is read from `bounds` here.
+__global__ void __launch_bounds__(256)
+k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long long* __restrict__ bounds, uint32_t rank,
+             uint32_t* __restrict__ lcp)
+{
+    __shared__ uint32_t s_first;
+    if (bounds[(size_t)rank * 3 + 2] == 0ull) return;
+    int prev = (int)rank - 1;
+    while (prev >= 0 && bounds[(size_t)prev * 3 + 2] == 0ull) prev--;
+    if (prev < 0) return;                                  // the globally first suffix: LCP 0, as the build left it
+    const uint64_t a = bounds[(size_t)prev * 3 + 1], b = bounds[(size_t)rank * 3];
+    const uint64_t lim = n - (a > b ? a : b);          // characters both suffixes have
+    for (uint64_t k = 0;; k += 4096) {
+        if (threadIdx.x == 0) s_first = 0xffffffffu;
+        __syncthreads();
+        const uint64_t o = k + (uint64_t)threadIdx.x * 16;
+        uint32_t m = 16;
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint64_t q = o + i;
+            if (q >= lim || text[a + q] != text[b + q]) { m = i; break; }
+        }
+        if (m < 16) atomicMin(&s_first, threadIdx.x * 16 + m);
+        __syncthreads();
+        const uint32_t f = s_first;
+        __syncthreads();
+        if (f != 0xffffffffu) { if (threadIdx.x == 0) lcp[0] = (uint32_t)(k + f); return; }
+    }
+}
+
 // widen u32 results for the u64-index ABI (texts below 2^32-1 only)
 __global__ void __launch_bounds__(256)
 k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t count)

@@ -26,6 +26,36 @@ def exchange_boundaries(first: int, last: int, count: int, device, dist=None) ->
     return [tuple(int(v) for v in t.tolist()) for t in out]
 
 
+def gather_boundaries_device(sa, count: int, dist=None):
+    """The same exchange without a host round trip: the triple is assembled on the device from the shard's own
+    suffix array (sa: the int32 / int64 tensor sufr_hip_sort_device_* filled, `count` entries valid) and gathered into
+    a [world, 3] int64 tensor that stays in device memory (backend nccl = RCCL; gloo accepts CPU tensors)."""
+    dev = sa.device
+    if count:
+        ends = torch.stack([sa[0], sa[count - 1]]).to(torch.int64) & 0xFFFFFFFF if sa.dtype == torch.int32 \
+            else torch.stack([sa[0], sa[count - 1]]).to(torch.int64)
+    else:
+        ends = torch.zeros(2, dtype=torch.int64, device=dev)
+    mine = torch.cat([ends, torch.tensor([count], dtype=torch.int64, device=dev)])
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return mine.view(1, 3)
+    out = torch.empty(dist.get_world_size(), 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), mine)
+    return out
+
+
+def stitch_device(ctx, text_len: int, bounds, rank: int, lcp) -> None:
+    """LCP[0] of this rank's device-resident shard := exact LCP with the last suffix of the nearest non-empty shard
+    before it (sufr_hip_stitch_device_u32: a kernel on the context's text; `bounds` = gather_boundaries_device's
+    tensor, on the GPU).  The gather ran on torch's stream, the kernel runs on the context's: wait for the former."""
+    from . import _lib
+    world = bounds.shape[0]
+    if world == 1 or rank == 0:
+        return
+    torch.cuda.current_stream(bounds.device).synchronize()
+    ctx.check(_lib.lib().sufr_hip_stitch_device_u32(ctx.handle, text_len, bounds.data_ptr(), rank, world, lcp.data_ptr()))
+
+
 def output_offset(boundaries: List[Boundary], rank: int) -> int:
     """Position of this shard's first entry in the concatenated SA / LCP arrays."""
     return sum(b[2] for b in boundaries[:rank])

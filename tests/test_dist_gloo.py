@@ -46,6 +46,13 @@ def _worker(rank, world, port, q, out_path):
                                             int(my_sa.size), torch.device("cpu"), dist)
         assert [b[2] for b in bounds] == [edges[i + 1] - edges[i] for i in range(world)]
         assert shards.output_offset(bounds, rank) == lo
+        # the form bench.py's timed N > 1 step uses: the triple is cut out of the shard's own array (no .item()) and
+        # gathered into ONE [world, 3] tensor (on a GPU it stays in HBM and feeds sufr_hip_stitch_device_u32)
+        dev_bounds = shards.gather_boundaries_device(torch.from_numpy(my_sa.astype(np.int64)), int(my_sa.size), dist)
+        assert dev_bounds.shape == (world, 3) and dev_bounds.dtype == torch.int64
+        assert [tuple(int(v) for v in row) for row in dev_bounds.tolist()] == list(bounds)
+        i32 = torch.from_numpy(my_sa.astype(np.uint32).view(np.int32))      # what the u32 ABI fills: int32-typed
+        assert torch.equal(shards.gather_boundaries_device(i32, int(my_sa.size), dist), dev_bounds)
         k = shards.stitched_first_lcp(bounds, rank, lambda st, ln: norm[st:st + ln], norm.size)
         if rank == 0:
             assert k is None

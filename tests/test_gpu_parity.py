@@ -484,6 +484,38 @@ def test_device_api_and_shards_concatenate(oracle):
     db.close()
 
 
+def test_device_stitch_sets_the_boundary_lcp_without_the_host(oracle):
+    """sufr_hip_stitch_device_u32 (the timed N > 1 step of bench.py): {first, last, count} of every shard in ONE
+    device tensor, LCP[0] of a shard set by a kernel on the context's text -- against the single build, with an
+    empty shard between two others (the kernel looks for the nearest non-empty one)."""
+    from sufr_amd import shards as sh
+    x, _ = synth.syn_human(2_000_000, seed=21)
+    raw = x.numpy()
+    db = sufr_amd.DeviceBuilder(0)
+    d_text = torch.from_numpy(raw).cuda()
+    fsa, flcp = (t.clone() for t in db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True))
+    for world in (2, 4):
+        parts, rows = [], []
+        for r in range(world):
+            psa, plcp = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, shard_index=r, num_shards=world)
+            parts.append((psa.clone(), plcp.clone()))
+            rows.append(sh.gather_boundaries_device(psa, int(psa.numel())))
+        # an empty shard squeezed in after shard 0: bounds rows {0, 0, 0}
+        bounds = torch.cat([rows[0], torch.zeros(1, 3, dtype=torch.int64, device="cuda")] + rows[1:]).contiguous()
+        off = 0
+        for r in range(world):
+            psa, plcp = parts[r]
+            # (the context's text is the one of the last build: the same text for every shard)
+            if r > 0:
+                plcp[0] = -1
+                sh.stitch_device(db.ctx, raw.size, bounds, r + 1, plcp)
+            assert torch.equal(psa, fsa[off:off + psa.numel()])
+            assert torch.equal(plcp, flcp[off:off + psa.numel()]), f"world {world} shard {r}"
+            off += psa.numel()
+        assert off == fsa.numel()
+    db.close()
+
+
 def test_options_on_a_5mb_genome(oracle, tmp_path):
     """-m and -s at a size where the tie runs fill many tiles (human-like repeats, 5 Mb)."""
     x, _ = synth.syn_human(5_000_000, seed=9)
@@ -724,6 +756,47 @@ def test_elegans_config_c3_equals_oracle(oracle):
     assert np.array_equal(sa.cpu().numpy().view(np.uint32), osa)
     assert np.array_equal(lcp.cpu().numpy().view(np.uint32), olcp)
     db.close()
+
+
+def test_seed_mask_build_at_100mb_equals_oracle(oracle):
+    """--seed-mask at the size of the reference's own large masked build (Makefile:82, `-s 111010010100110111`): the
+    100 Mb C3 stand-in, whole SA and whole LCP against the oracle (which orders by the care characters and breaks ties
+    by descending position, sufr_builder.rs:272-300, 701-712)."""
+    mask = "111010010100110111"
+    x, _ = synth.syn_elegans(100_286_401, seed=2, device="cuda")
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True, raw_text=True, num_partitions=64, seed_mask=mask)
+    norm = oracle.normalize(x.cpu().numpy(), False)
+    osa, olcp, _ = oracle.build(norm, is_dna=True, num_partitions=64, seed_mask=mask, threads=os.cpu_count() or 1)
+    assert np.array_equal(sa.cpu().numpy().view(np.uint32), osa)
+    assert np.array_equal(lcp.cpu().numpy().view(np.uint32), olcp)
+    db.close()
+
+
+def test_bench_reads_a_real_fasta_through_the_package_reader(tmp_path):
+    """SUFR_BENCH_FASTA (real assemblies only if present on the box): bench.py must parse the file with
+    the package's own reader, build it with the workload's flags and label the line `"data": "real"`."""
+    import json
+    import subprocess
+    x, _ = synth.syn_human(300_000, seed=11)
+    body = x.numpy()[:-1]
+    fa = tmp_path / "tiny.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chrA test\n")
+        for i in range(0, 200_000, 70):
+            f.write(body[i:min(i + 70, 200_000)].tobytes() + b"\n")
+        f.write(b">chrB\n" + body[200_000:].tobytes() + b"\n")
+    env = dict(os.environ, SUFR_BENCH_FASTA=str(fa))
+    import sys
+    from pathlib import Path
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--workload", "human", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-e2e", "--no-search", "--placement-trials", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-400:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["data"] == "real" and "tiny.fa (2 sequences)" in line["config"]["workload"]
+    assert line["config"]["text_len"] == body.size + 2            # the delimiter and the sentinel
+    assert line["verified"]["ranks"] > 0               # the arrays of the timed step were checked against the text
 
 
 def test_human_prefix_400mb_section_hashes_equal_oracle(oracle):
