@@ -229,7 +229,11 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx *ctx, const sufr_sequence_data *s
  *
  * One process per GPU (torch.distributed / MPI ranks): every rank calls sufr_hip_shard_build, the ranks exchange
  * their sufr_shard_info (24 bytes each: the only collective of the path), rank 0 calls sufr_write_frame, and after
- * a barrier every rank calls sufr_hip_shard_write with the suffix count of the ranks before it. */
+ * a barrier every rank calls sufr_hip_shard_write with the suffix count of the ranks before it.
+ *
+ * Device memory of one shard of N (text of n bytes, s suffixes in all): the text and its packed / bitmap forms
+ * (~1.6 n), SA + LCP of the shard (8 s / N, sized from the shard's exact count), two record arrays (24 s / N) and the
+ * level workspace -- the text is replicated, everything else scales with 1 / N. */
 typedef struct sufr_shard_info {
     uint64_t num_suffixes;      /* suffixes of this shard */
     uint64_t first_suffix;      /* SA[0] of the shard (undefined when it is empty) */

@@ -9,10 +9,14 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "_build" / "libsufr_hip.so"
-# profiles/*.py may point the binding at the probes build (tuning knobs from SUFR_PROBE_*); the package and the
-# tests always use the plain library, which reads no environment besides SUFR_HIP_DEBUG and SUFR_SERIAL_READER
+# profiles/*.sh may point the binding at the probes build (tuning knobs from SUFR_PROBE_*, phase stamps); the tests and
+# the driver use the plain library, which reads no environment besides SUFR_HIP_DEBUG and SUFR_SERIAL_READER.  The
+# switch is loud: a stray variable must not change a user's kernels silently.
 if os.environ.get("SUFR_AMD_PROBES_LIB"):
+    import sys as _sys
     LIB_PATH = CSRC / "_build" / "libsufr_hip_probes.so"
+    print(f"sufr_amd: SUFR_AMD_PROBES_LIB is set -- loading the PROBES build {LIB_PATH.name} (tuning knobs from "
+          "SUFR_PROBE_*; for profiling only)", file=_sys.stderr)
 CLI_PATH = CSRC / "_build" / "sufr"
 
 

@@ -100,7 +100,13 @@ std::vector<std::string> expand_queries(const std::vector<std::string>& args)
     for (const std::string& a : args) {
         struct stat sb;
         if (stat(a.c_str(), &sb) == 0) {
+            // an argument that names something on disk is a file of queries (sufr/src/lib.rs: the path is opened and
+            // read; a directory or an unreadable file is an error there too, not an empty query list)
             std::ifstream in(a);
+            if (!S_ISREG(sb.st_mode) || !in) {
+                fprintf(stderr, "Error: %s: %s\n", a.c_str(), S_ISDIR(sb.st_mode) ? "Is a directory" : "cannot read the query file");
+                exit(1);
+            }
             std::string w;
             while (in >> w) out.push_back(w);
         } else out.push_back(a);

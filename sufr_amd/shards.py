@@ -108,19 +108,45 @@ def create_sharded(ctx, seq, args, outfile: str, rank: int, world: int, dist, de
     from . import _lib
     L = _lib.lib()
     info = _lib.ShardInfo(); st = _lib.Stats()
-    ctx.check(L.sufr_hip_shard_build(ctx.handle, C.byref(seq), C.byref(args), rank, world, C.byref(info), C.byref(st)))
+    multi = dist is not None and dist.is_initialized() and world > 1
+    path = os.fsencode(outfile)
+
+    def agree(err):
+        """Every rank learns whether ANY rank failed this step (one all_reduce): a rank that raised alone would leave
+        the others waiting in the next collective for ever.  Rank 0 removes the output, then everybody raises."""
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=device)
+        if multi:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if rank == 0:
+                try:
+                    os.unlink(outfile)
+                except OSError:
+                    pass
+            if err is not None:
+                raise err
+            raise _lib.SufrHipError(-1, "another rank failed; the output file was removed")
+
+    err = None
+    try:
+        ctx.check(L.sufr_hip_shard_build(ctx.handle, C.byref(seq), C.byref(args), rank, world, C.byref(info), C.byref(st)))
+    except Exception as e:          # noqa: BLE001 -- reported to every rank below
+        err = e
+    agree(err)
     bounds = exchange_boundaries(int(info.first_suffix), int(info.last_suffix), int(info.num_suffixes), device, dist)
     offset, total, has_prev, prev_last = write_plan(bounds, rank)
-    path = os.fsencode(outfile)
+    err = None
     if rank == 0:
-        err = C.create_string_buffer(512)
-        rc = L.sufr_write_frame(path, C.byref(seq), C.byref(args), total, err, len(err))
+        buf = C.create_string_buffer(512)
+        rc = L.sufr_write_frame(path, C.byref(seq), C.byref(args), total, buf, len(buf))
         if rc != 0:
-            raise _lib.SufrHipError(rc, err.value.decode())
-    if dist is not None and dist.is_initialized() and world > 1:
-        dist.barrier()
-    ctx.check(L.sufr_hip_shard_write(ctx.handle, C.byref(seq), C.byref(args), path, int(info.num_suffixes), total,
-                                     offset, int(has_prev), prev_last, int(rank == 0)))
-    if dist is not None and dist.is_initialized() and world > 1:
-        dist.barrier()
+            err = _lib.SufrHipError(rc, buf.value.decode())
+    agree(err)                      # (also the barrier: the frame exists before any rank writes its slice)
+    err = None
+    try:
+        ctx.check(L.sufr_hip_shard_write(ctx.handle, C.byref(seq), C.byref(args), path, int(info.num_suffixes), total,
+                                         offset, int(has_prev), prev_last, int(rank == 0)))
+    except Exception as e:          # noqa: BLE001
+        err = e
+    agree(err)                      # a failed slice leaves a valid header over missing arrays: the file goes
     return bounds, st

@@ -106,12 +106,27 @@ class SufrFile:
             raw = C.string_at(L.sufr_file_seed_mask(h), m.seed_mask_len)
             self.seed_mask = "".join("1" if b == 1 else "0" for b in raw)
 
-    # -- views into the mapping (valid until close) --------------------------------------------------------------------
+    # -- views into the mapping --------------------------------------------------------------------------------------
+    # Zero-copy: the arrays alias the mapped file.  Every view keeps the mapping alive -- it holds a reference to this
+    # object (so `SufrFile(p).suffix_array.tolist()` works), and close() / __del__ only unmap once the last view is
+    # gone (a close() with views outstanding is deferred to the last view's finaliser).
     def _view(self, ptr, count, dtype):
         if count == 0:
             return np.empty(0, dtype=dtype)
+        import weakref
         buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
-        return np.frombuffer(buf, dtype=dtype)
+        buf._owner = self
+        arr = np.frombuffer(buf, dtype=dtype)
+        self._live_views = getattr(self, "_live_views", 0) + 1
+        weakref.finalize(buf, SufrFile._view_gone, self)
+        return arr
+
+    @staticmethod
+    def _view_gone(owner):
+        owner._live_views -= 1
+        if owner._live_views == 0 and getattr(owner, "_close_pending", False):
+            owner._close_pending = False
+            owner.close()
 
     @property
     def text(self) -> np.ndarray:
@@ -126,6 +141,9 @@ class SufrFile:
         return self._view(lib().sufr_file_lcp_array(self._h), self.len_suffixes, np.uint32 if self.index_width == 4 else np.uint64)
 
     def close(self):
+        if getattr(self, "_live_views", 0) > 0:          # arrays still alias the mapping: unmap when the last one goes
+            self._close_pending = True
+            return
         if getattr(self, "_h", None):
             lib().sufr_file_close(self._h)
             self._h = None
