@@ -169,30 +169,59 @@ SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
 {
     // q >= pi >= 1 and q <= n.  The text is padded, so loads next to q are issued without bounds checks.
     uint32_t rem = 0;
-    if (pi == 1) {
-        const uint32_t cprev = text[q - 1], cq = text[q];
-        if (q < n && cq == cprev) rem = run_len_at(q, rt);
-    } else {
-        rem = periodic_rem(text, n, q, pi);
-    }
-    const uint64_t after = q + rem;                    // <= n
-    const uint8_t* ta = text + after;
-    const uint32_t x = ta[0];
-    const uint32_t c = ta[-(int)pi];                   // what the periodic extension predicts at `after`
-    // `packed` (optional): the whole text as a big-endian stream of `bits`-bit codes, zero past the end;
-    // the characters after the run are then one unaligned 9-byte read instead of a per-character loop
     uint64_t pw = 0; uint32_t pw2 = 0; uint32_t ps = 0;
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    if (packed) {
-        const uint64_t o = after * (uint64_t)bits;
-        const uint8_t* pp = packed + (o >> 3);
-        ps = (uint32_t)(o & 7u);
-        pw = __builtin_bswap64(load_u64_unaligned(pp));
-        pw2 = pp[8];
+    uint64_t after;
+    uint32_t x, c;
+    if (packed && pi == 1) {
+        // Everything from the packed code stream (codes are the ranks of the bytes: equal codes <=> equal bytes, code
+        // order = byte order): the codes at q - 1, q and the ~20 after them are ONE unaligned 16-byte read -- one
+        // 64-byte sector of a random suffix instead of one in the byte text plus one in the packed stream.  Only a
+        // run (text[q] == text[q - 1]) costs more: the run-end table, then the same read behind the run.
+        auto codes_at = [&](uint64_t p, uint64_t& from_p, uint64_t& from_next) {     // 64 bits of codes from p / p + 1 on
+            const uint64_t o = p * (uint64_t)bits;
+            const uint8_t* pp = packed + (o >> 3);
+            const uint32_t s0 = (uint32_t)(o & 7u), s1 = s0 + (uint32_t)bits;        // s1 <= 11
+            const uint64_t hi = __builtin_bswap64(load_u64_unaligned(pp)), lo = __builtin_bswap64(load_u64_unaligned(pp + 8));
+            from_p = s0 ? ((hi << s0) | (lo >> (64 - s0))) : hi;
+            from_next = (hi << s1) | (lo >> (64 - s1));
+        };
+        uint64_t vprev, vq;
+        codes_at(q - 1, vprev, vq);
+        uint32_t cprev = (uint32_t)(vprev >> (64 - bits)), cq = (uint32_t)(vq >> (64 - bits));
+        if (q < n && cq == cprev) {
+            rem = run_len_at(q, rt);
+            codes_at(q + rem - 1, vprev, vq);
+            cprev = (uint32_t)(vprev >> (64 - bits)); cq = (uint32_t)(vq >> (64 - bits));
+        }
+        after = q + rem;
+        x = cq; c = cprev;
+        pw = vq;                                           // codes from `after` on (ps = 0)
     } else {
-        w0 = load_u64_unaligned(ta); w1 = load_u64_unaligned(ta + 8);
-        w2 = load_u64_unaligned(ta + 16); w3 = load_u64_unaligned(ta + 24);
+        if (pi == 1) {
+            const uint32_t cprev = text[q - 1], cq = text[q];
+            if (q < n && cq == cprev) rem = run_len_at(q, rt);
+        } else {
+            rem = periodic_rem(text, n, q, pi);
+        }
+        after = q + rem;                               // <= n
+        const uint8_t* ta = text + after;
+        x = ta[0];
+        c = ta[-(int)pi];                              // what the periodic extension predicts at `after`
+        // `packed` (optional): the whole text as a big-endian stream of `bits`-bit codes, zero past the end;
+        // the characters after the run are then one unaligned 9-byte read instead of a per-character loop
+        if (packed) {
+            const uint64_t o = after * (uint64_t)bits;
+            const uint8_t* pp = packed + (o >> 3);
+            ps = (uint32_t)(o & 7u);
+            pw = __builtin_bswap64(load_u64_unaligned(pp));
+            pw2 = pp[8];
+        } else {
+            w0 = load_u64_unaligned(ta); w1 = load_u64_unaligned(ta + 8);
+            w2 = load_u64_unaligned(ta + 16); w3 = load_u64_unaligned(ta + 24);
+        }
     }
+    const uint8_t* ta = text + after;
     const uint32_t cls = (after < n && x > c) ? 1u : 0u;
     const uint32_t v = rem + 1u;
     const int L = 31 - __builtin_clz(v);
