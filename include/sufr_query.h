@@ -68,7 +68,8 @@ int sufr_file_search_batch(const sufr_file *f, const uint8_t *queries, const uin
 /* ---- the same search for a batch of queries, on the GPU ---------------------------------------------------------
  * Replaces the rayon loop of SuffixArray::count / locate (libsufr/src/suffix_array.rs:181-236, 340-366;
  * sufr_file.rs:760-800): text and suffix array are resident in HBM, one launch answers the batch, one lane per
- * query.  32-bit suffix arrays only (text_len < 2^32 - 1), like the device builder.
+ * query.  Suffix arrays of both widths (u32 iff text_len < 2^32 - 1, suffix_array.rs:460-470; d_positions of
+ * sufr_hip_locate_batch_device has the width of the array).
  *
  * sufr_hip_index_load   copies text + SA (+ seed mask) of an open file to the context's device.
  * sufr_hip_index_wrap   wraps arrays that are already on the device -- e.g. the normalized text handed to
@@ -85,6 +86,7 @@ int sufr_file_search_batch(const sufr_file *f, const uint8_t *queries, const uin
 typedef struct sufr_hip_index sufr_hip_index;
 int  sufr_hip_index_load(sufr_hip_ctx *ctx, const sufr_file *f, sufr_hip_index **out);
 #define SUFR_HIP_FLAG_NO_PREFIX_TABLE 0x100u
+#define SUFR_HIP_FLAG_SA_U64 0x200u          /* sufr_hip_index_wrap: d_sa holds u64 entries although text_len < 2^32 - 1 */
 int  sufr_hip_index_wrap(sufr_hip_ctx *ctx, const void *d_text, uint64_t text_len, const void *d_sa, uint64_t num_suffixes,
                          uint32_t flags, uint64_t built_max_query_len, const char *seed_mask, sufr_hip_index **out);
 void sufr_hip_index_free(sufr_hip_index *ix);
@@ -98,7 +100,7 @@ int  sufr_hip_search_batch_device(sufr_hip_ctx *ctx, const sufr_hip_index *ix, c
 /* locate: the positions behind the rank ranges of a batch (SufrFile::locate, sufr_file.rs:1110-1175, without the
  * sequence names: those are a host lookup per position, sufr_file_sequence_of).  For query i the suffixes
  * SA[lo_i .. min(hi_i, lo_i + max_hits)) in rank order (max_hits 0: all) land in d_positions[d_offsets[i] .. d_offsets[i+1]);
- * d_offsets holds num_queries + 1 u64, d_positions up to `cap` u32.  *total_out = d_offsets[num_queries] even when it
+ * d_offsets holds num_queries + 1 u64, d_positions up to `cap` entries of the index's width.  *total_out = d_offsets[num_queries] even when it
  * exceeds cap (the call then returns SUFR_HIP_E_CAPACITY and gathers nothing).  Enqueued on the context's stream after
  * one synchronisation for the total. */
 int  sufr_hip_locate_batch_device(sufr_hip_ctx *ctx, const sufr_hip_index *ix, const void *d_rank_lo, const void *d_rank_hi,

@@ -65,6 +65,7 @@ class ShardInfo(C.Structure):
 
 FLAG_DNA, FLAG_ALLOW_AMBIGUITY, FLAG_IGNORE_SOFTMASK, FLAG_RAW_TEXT = 1, 2, 4, 8
 FLAG_NO_PREFIX_TABLE = 0x100      # sufr_hip_index_wrap only
+FLAG_SA_U64 = 0x200               # sufr_hip_index_wrap only: 64-bit suffix array of a text below 2^32 - 1 bytes
 
 # every symbol include/sufr_hip.h declares
 EXPORTS = [

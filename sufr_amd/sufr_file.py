@@ -283,21 +283,29 @@ class DeviceIndex:
     def load(cls, ctx: Context, f: SufrFile) -> "DeviceIndex":
         h = C.c_void_p()
         ctx.check(lib().sufr_hip_index_load(ctx.handle, f._h, C.byref(h)))
-        return cls(ctx, h)
+        ix = cls(ctx, h)
+        ix.index_width = f.index_width
+        return ix
 
     @classmethod
     def wrap(cls, ctx: Context, text, sa, max_query_len: int = 0, seed_mask: Optional[str] = None, is_dna: bool = False,
              prefix_table: bool = True) -> "DeviceIndex":
         import torch
-        if not (text.is_cuda and sa.is_cuda and text.dtype == torch.uint8 and sa.dtype in (torch.int32, torch.uint32)):
-            raise ValueError("wrap() takes a uint8 text and a 32-bit suffix array on the GPU")
+        if not (text.is_cuda and sa.is_cuda and text.dtype == torch.uint8 and
+                sa.dtype in (torch.int32, torch.uint32, torch.int64, torch.uint64)):
+            raise ValueError("wrap() takes a uint8 text and a 32- or 64-bit suffix array on the GPU")
+        wide = sa.dtype in (torch.int64, torch.uint64)
+        if (text.numel() >= 0xFFFFFFFF) and not wide:
+            raise ValueError("texts of 2^32 - 1 bytes and more have 64-bit suffix arrays (suffix_array.rs:460-470)")
         h = C.c_void_p()
-        from ._lib import FLAG_DNA, FLAG_NO_PREFIX_TABLE
+        from ._lib import FLAG_DNA, FLAG_NO_PREFIX_TABLE, FLAG_SA_U64
         torch.cuda.current_stream(text.device).synchronize()      # the table is built from the arrays right away
-        flags = (FLAG_DNA if is_dna else 0) | (0 if prefix_table else FLAG_NO_PREFIX_TABLE)
+        flags = (FLAG_DNA if is_dna else 0) | (0 if prefix_table else FLAG_NO_PREFIX_TABLE) | (FLAG_SA_U64 if wide else 0)
         ctx.check(lib().sufr_hip_index_wrap(ctx.handle, text.data_ptr(), text.numel(), sa.data_ptr(), sa.numel(), flags,
                                             max_query_len, seed_mask.encode() if seed_mask else None, C.byref(h)))
-        return cls(ctx, h, keep=(text, sa))
+        ix = cls(ctx, h, keep=(text, sa))
+        ix.index_width = 8 if wide else 4
+        return ix
 
     def close(self):
         if getattr(self, "_h", None):
@@ -354,7 +362,8 @@ class DeviceIndex:
         if capacity is None:                                   # size the output from the counts
             cnt = hi - lo
             capacity = int((cnt.clamp(max=max_hits) if max_hits else cnt).sum())
-        pos = torch.empty(max(capacity, 1), dtype=torch.int32, device=lo.device)
+        pos = torch.empty(max(capacity, 1), dtype=torch.int64 if getattr(self, "index_width", 4) == 8 else torch.int32,
+                          device=lo.device)
         self.ctx.check(lib().sufr_hip_locate_batch_device(self.ctx.handle, self._h, lo.data_ptr(), hi.data_ptr(), nq, max_hits,
                                                          off.data_ptr(), pos.data_ptr(), capacity, C.byref(total)))
         self.ctx.synchronize()

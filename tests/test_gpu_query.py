@@ -159,10 +159,12 @@ def test_build_then_query_without_leaving_the_device(ctx, tmp_path):
     db.close()
 
 
-def test_index_of_another_width_or_device_is_refused(ctx):
+def test_index_of_another_type_or_device_is_refused(ctx):
     x = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):                       # (64-bit arrays are taken since round 3; 16-bit ones are not)
+        DeviceIndex.wrap(ctx, x, torch.zeros(4, dtype=torch.int16, device="cuda"))
     with pytest.raises(ValueError):
-        DeviceIndex.wrap(ctx, x, torch.zeros(4, dtype=torch.int64, device="cuda"))
+        DeviceIndex.wrap(ctx, x.cpu(), torch.zeros(4, dtype=torch.int32, device="cuda"))
 
 
 # the reference's CLI expectations once more, searched as a batch on the GPU (`--device 0`)
@@ -207,3 +209,35 @@ def test_device_locate_equals_host_locate(ctx, name):
         ix.locate_device(lo, hi, capacity=total - 1)
     assert e.value.code == -5 and str(total) in e.value.message
     ix.close()
+
+
+def test_device_search_on_64_bit_suffix_arrays(tmp_path):
+    """The u64 arm of the file format (suffix_array.rs:460-470) on the device: the same text built with 32- and with
+    64-bit indices gives the same rank ranges and the same positions, from a wrapped array and from a loaded file
+    (the reference's u64 KAT input, lib.rs:94-140, written with index width 8 by the windowed build)."""
+    import torch
+    from sufr_amd import synth
+    x, _ = synth.syn_human(400_000, seed=31)
+    raw = x.numpy()
+    db = sufr_amd.DeviceBuilder(0)
+    d_text = torch.from_numpy(raw).cuda()
+    sa32, _ = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True)
+    sa32 = sa32.clone()
+    sa64, _ = db.sort(d_text, is_dna=True, ignore_softmask=True, raw_text=True, index_width=8)
+    assert sa64.dtype == torch.int64 and torch.equal(sa64, sa32.to(torch.int64) & 0xFFFFFFFF)
+    norm = torch.from_numpy(sufr_amd.normalize(raw, True)).cuda()
+    text = norm.cpu().numpy().tobytes()
+    rng = np.random.default_rng(5)
+    queries = [text[i:i + int(L)] for i, L in zip(rng.integers(0, len(text) - 40, 3000), rng.integers(1, 40, 3000))]
+    queries += [b"ACGTTTTTTGGGGGGGGGGCA", b"N" * 30, b"$"]
+    a = sufr_amd.DeviceIndex.wrap(db.ctx, norm, sa32, is_dna=True)
+    b = sufr_amd.DeviceIndex.wrap(db.ctx, norm, sa64, is_dna=True)
+    lo_a, hi_a = a.search(queries)
+    lo_b, hi_b = b.search(queries)
+    assert np.array_equal(lo_a, lo_b) and np.array_equal(hi_a, hi_b) and int((hi_a > lo_a).sum()) > 1000   # (queries that start inside masked stretches match no suffix start)
+    dl = torch.from_numpy(lo_a.astype(np.int64)).cuda(); dh = torch.from_numpy(hi_a.astype(np.int64)).cuda()
+    off_a, pos_a = a.locate_device(dl, dh, max_hits=7)
+    off_b, pos_b = b.locate_device(dl, dh, max_hits=7)
+    assert pos_b.dtype == torch.int64 and torch.equal(off_a, off_b)
+    assert torch.equal(pos_b[:int(off_b[-1])], pos_a[:int(off_a[-1])].to(torch.int64) & 0xFFFFFFFF)
+    a.close(); b.close(); db.close()
