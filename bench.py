@@ -199,7 +199,9 @@ def e2e_create_sharded(text, starts, flags: dict, partitions: int, rank: int, wo
         return {"seconds": float(t[0]), "read_seconds": float(t[1]), "suffixes_per_s": s_total / float(t[0]),
                 "sufr_bytes": out.stat().st_size if rank == 0 else None, "shard_suffixes": [b[2] for b in bounds],
                 "what": f"{world} ranks, one GPU each: FASTA parse (every rank), H2D, shard build, 24-byte all_gather, "
-                        "D2H + every rank's slice written into the one .sufr file (contexts already up)"}
+                        "D2H + every rank's slice written into the one .sufr file (contexts already up).  WRITE-BOUND: the "
+                        "file is 8 bytes per suffix + the text and the page cache of one host takes ~11-15 GB/s whoever "
+                        "writes; the builds are < 5 % of it, so this figure does not scale with the number of GPUs"}
     except Exception as e:
         return {"error": repr(e)[:300]}
     finally:
