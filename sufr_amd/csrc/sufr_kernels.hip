@@ -456,17 +456,18 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
     }
 }
 
-// rawtot[v] = suffix starts whose first digit is v (all groups); flags[v] = 1 iff the 5-mer v occurs anywhere
+// rawtot[v] = suffix starts whose first digit is v (all groups); bit v of occurs[] set iff the 5-mer v occurs anywhere
+// (4 KB: what a single-GPU build reads back -- the counts themselves only decide shard ranges)
 __global__ void __launch_bounds__(256)
 k_fold_raw(const uint32_t* __restrict__ rawtab, uint32_t ngroups, const uint32_t* __restrict__ presbits,
-           uint32_t* __restrict__ rawtot, uint32_t* __restrict__ flags)
+           uint32_t* __restrict__ rawtot, unsigned long long* __restrict__ occurs)
 {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= (uint32_t)TP_RAW_BINS) return;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;          // TP_RAW_BINS is a multiple of 256
     uint32_t t = 0;
     for (uint32_t g = 0; g < ngroups; g++) t += rawtab[(size_t)g * TP_RAW_BINS + v];
     rawtot[v] = t;
-    flags[v] = (t || ((presbits[v >> 5] >> (v & 31u)) & 1u)) ? 1u : 0u;
+    const uint64_t m = __ballot(t || ((presbits[v >> 5] >> (v & 31u)) & 1u));
+    if (lane_id() == 0) occurs[v >> 6] = m;
 }
 
 // grouptab[g][d] = suffix starts of group g whose first digit has dense value d: the raw values
