@@ -4,7 +4,13 @@
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; C=${1:-human_dna}; MIN=${2:-500}
 mkdir -p $R/gpurun_out
-rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 $R/profiles/input_classes.py $C > /tmp/prof_tl.log 2>&1
+# (class "bench:<workload>" traces bench.py --workload <workload> instead)
+if [ "${C#bench:}" != "$C" ]; then
+  CMD="python3 $R/bench.py --workload ${C#bench:} --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --placement-trials 1"
+else
+  CMD="python3 $R/profiles/input_classes.py $C"
+fi
+rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- $CMD > /tmp/prof_tl.log 2>&1
 grep "^$C" /tmp/prof_tl.log
 python3 - $MIN <<'PY' | tee $R/gpurun_out/kt_timeline.txt
 import csv, glob, sys

@@ -801,10 +801,6 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* s
         return SUFR_HIP_E_CONFLICT;
     }
     const uint64_t n = sd.seq_len;
-    if ((a->has_max_query_len && a->max_query_len > 0) || a->seed_mask) {      // before any allocation: windows cannot order their ties
-        sufr_hip_set_error_(ctx, "max_query_len / seed_mask builds need the whole text in one 32-bit window (text_len < 2^32 - 2^24)");
-        return SUFR_HIP_E_UNSUPPORTED;
-    }
     const int width = n < 0xFFFFFFFFull ? 4 : 8;
     std::vector<uint8_t> norm(n);
     uint64_t s = 0;

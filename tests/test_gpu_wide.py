@@ -99,19 +99,52 @@ def test_cli_create_in_windows_writes_the_golden_file(tmp_path, name):
     assert out.read_bytes() == (GOLDEN / "expected" / name).read_bytes()
 
 
-def test_masked_and_truncated_builds_are_refused_in_windows():
-    t = torch.from_numpy(repeat_text(20_000, 4, 100, 5)).cuda()
-    db = sufr_amd.DeviceBuilder(0)
-    db.ctx.set_window(4096, 64)
-    with pytest.raises(sufr_amd.SufrHipError) as e:
-        db.sort(t, is_dna=True, max_query_len=8)
-    assert e.value.code == -6 and "one 32-bit window" in e.value.message
-    with pytest.raises(sufr_amd.SufrHipError):
-        db.sort(t, is_dna=True, seed_mask="1101")
-    db.ctx.set_window(0, 0)                                   # back to one window: the same context builds them
-    sa, _ = db.sort(t, is_dna=True, max_query_len=8)
-    assert sa.numel() > 0
-    db.close()
+@pytest.mark.parametrize("index_width", [4, 8])
+@pytest.mark.parametrize("window,margin", [(4096, 64), (5000, 3000), (20000, 100), (4000, 8)])
+def test_seed_mask_build_in_windows_equals_oracle(oracle, window, margin, index_width):
+    """--seed-mask across windows (find_lcp's mask arm, sufr_builder.rs:272-300): the windows are built with the mask and
+    merged under the masked order; margins shorter than the mask are widened to its span"""
+    t = repeat_text(60_000, 1, 900, 40)
+    for mask in ["1101", "10111011", "111010010100110111"]:
+        want_sa, want_lcp, _ = oracle.build(t, is_dna=True, seed_mask=mask, threads=8)
+        sa, lcp, st = build(torch.from_numpy(t).cuda(), window, margin, index_width, is_dna=True, seed_mask=mask)
+        assert np.array_equal(sa, want_sa.astype(np.uint64)), mask
+        assert np.array_equal(lcp, want_lcp.astype(np.uint64)), mask
+        assert st.num_suffixes == sa.size
+
+
+@pytest.mark.parametrize("index_width", [4, 8])
+@pytest.mark.parametrize("window,margin", [(4096, 64), (5000, 3000), (20000, 100), (30000, 16)])
+@pytest.mark.parametrize("L", [1, 8, 21, 100, 1500])
+def test_max_query_len_build_in_windows_is_the_canonical_form(window, margin, index_width, L):
+    """--max-query-len across windows: the same canonical member of the reference's family as the one-window build
+    (tests/test_gpu_parity.py::test_max_query_len_canonical_form) -- first L symbols in order, ties in descending position
+    over the WHOLE text, LCP capped at L.  L above the margin exercises the retry with the widest margin; L = 1500 is
+    longer than the 900-symbol repeat, i.e. the plain order"""
+    t = repeat_text(60_000, 1, 900, 40)
+    x = torch.from_numpy(t).cuda()
+    one_sa, one_lcp, _ = build(x, 0, 0, index_width, is_dna=True, max_query_len=L)
+    sa, lcp, _ = build(x, window, margin, index_width, is_dna=True, max_query_len=L)
+    assert np.array_equal(sa, one_sa) and np.array_equal(lcp, one_lcp)
+    full_sa, full_lcp, _ = build(x, 0, 0, index_width, is_dna=True)
+    assert np.array_equal(lcp, np.minimum(full_lcp, L))
+    tie = lcp >= L
+    assert np.all(sa[1:][tie[1:]] < sa[:-1][tie[1:]])
+
+
+def test_masked_and_truncated_builds_of_a_protein_text_in_three_windows(oracle):
+    rng = np.random.default_rng(9)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    t = aa[rng.integers(0, 20, 30_000)].copy()
+    t[5000:9000] = t[20000:24000]
+    t[::997] = ord("%")
+    t[-1] = ord("$")
+    want_sa, want_lcp, _ = oracle.build(t, seed_mask="110101", threads=8)
+    sa, lcp, _ = build(torch.from_numpy(t).cuda(), 11_000, 300, 8, seed_mask="110101")
+    assert np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
+    one_sa, one_lcp, _ = build(torch.from_numpy(t).cuda(), 0, 0, 8, max_query_len=5)
+    sa, lcp, _ = build(torch.from_numpy(t).cuda(), 11_000, 300, 8, max_query_len=5)
+    assert np.array_equal(sa, one_sa) and np.array_equal(lcp, one_lcp)
 
 
 def test_medium_windowed_build_properties():
@@ -164,18 +197,51 @@ def test_text_beyond_32_bits():
     res = verify.check_sampled_ranks(x, sa, lcp, samples=400_000, deep_samples=100_000, deep_min_lcp=40)
     assert res["deep_ranks"] > 0 and res["max_lcp_checked"] >= 40_000
     print(f"4.4e9-byte text: {st.ms_total:.0f} ms device total, {res}")
+    # the same text under the reference's `hu-mask` seed (Makefile:82): windows built with the mask, merged under the masked
+    # order.  Sampled neighbours: care symbols in order, equal ones in descending position, LCP = equal care symbols.
+    del sa, lcp
+    torch.cuda.empty_cache()
+    mask = "111010010100110111"
+    try:
+        msa, mlcp = db.sort(x, is_dna=True, index_width=8, seed_mask=mask)
+    except (sufr_amd.SufrHipError, torch.OutOfMemoryError) as e:
+        if isinstance(e, sufr_amd.SufrHipError) and e.code != -4:
+            raise
+        pytest.skip(f"not enough free HBM for the masked 4.4e9-byte build: {e}")
+    assert verify.check_permutation(x, msa, is_dna=True, raw_is_normalised=True) == msa.numel() == count
+    offs = torch.tensor([i for i, c in enumerate(mask) if c == "1"], device=dev)
+    g2 = torch.Generator(device=dev); g2.manual_seed(11)
+    pick = torch.randint(1, msa.numel(), (400_000,), generator=g2, device=dev)
+    a, b = msa[pick - 1], msa[pick]
+    ok = (a + len(mask) < n) & (b + len(mask) < n)            # (the last few suffixes: care symbols past the end, covered at 60 kb)
+    a, b, w = a[ok], b[ok], mlcp[pick][ok]
+    ka, kb = x[a[:, None] + offs[None, :]].to(torch.int16), x[b[:, None] + offs[None, :]].to(torch.int16)
+    diff = ka != kb
+    anyd = diff.any(1)
+    first = torch.where(anyd, diff.to(torch.uint8).argmax(1), torch.full_like(a, offs.numel()))
+    assert bool((w == first).all())
+    fd = first.clamp(max=offs.numel() - 1)[:, None]
+    in_order = torch.where(anyd, ka.gather(1, fd)[:, 0] < kb.gather(1, fd)[:, 0], b < a)
+    assert bool(in_order.all())
+    assert int((~anyd).sum()) > 1000                          # ties across the whole text were among the samples
+    print(f"4.4e9-byte text, seed mask: {db.stats.ms_total:.0f} ms device total, {int((~anyd).sum())} of {int(ok.sum())} sampled pairs tie")
     db.close()
-    del x, sa, lcp
+    del x, msa, mlcp
     torch.cuda.empty_cache()
 
 
-def test_cli_refuses_masked_builds_in_windows_before_building(tmp_path):
+def test_cli_creates_masked_and_truncated_files_in_windows(tmp_path):
+    """`sufr create --window ... -m / -s`: the file of the windowed build is the file of the one-window build, byte for byte
+    (for the mask that is the reference's own family member: uniprot-masked.sufr is pinned in test_gpu_parity.py)"""
     fa = GOLDEN / "inputs" / "long_dna_sequence.fa"
-    for extra in (["-m", "8"], ["-s", "1101"]):
-        r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(tmp_path / "x.sufr"), "--window", "4096", *extra],
+    for tag, extra in (("m", ["-m", "8"]), ("s", ["-s", "1101"])):
+        one, win = tmp_path / f"one_{tag}.sufr", tmp_path / f"win_{tag}.sufr"
+        r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(one), *extra], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(win), "--window", "4096", "--margin", "48", *extra],
                            capture_output=True, text=True)
-        assert r.returncode == 1 and "one 32-bit window" in r.stderr
-        assert not (tmp_path / "x.sufr").exists()
+        assert r.returncode == 0, r.stderr
+        assert win.read_bytes() == one.read_bytes()
     r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(tmp_path / "y.sufr"), "--window", "4096", "-m", "0"],
                        capture_output=True, text=True)                                   # Some(0): a plain build
     assert r.returncode == 0, r.stderr
