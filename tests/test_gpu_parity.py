@@ -429,6 +429,37 @@ def test_many_copies_of_a_long_repeat(ctx, oracle, case):
         assert_matches_oracle(ctx, oracle, raw, allow_ambiguity=True)
 
 
+def _families_text(seed, n, families):
+    """random DNA with high-copy repeat families: (unit length, copies, mutation rate) each, copies placed at random"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = acgt[rng.integers(0, 4, n)]
+    for unit, copies, mut in families:
+        fam = acgt[rng.integers(0, 4, unit)]
+        at = rng.integers(0, n - unit - 1, copies)
+        for a in at:
+            c = fam.copy()
+            if mut:
+                hit = rng.random(unit) < mut
+                c[hit] = acgt[rng.integers(0, 4, int(hit.sum()))]
+            t[a:a + unit] = c
+    return np.concatenate([t, np.frombuffer(b"$", dtype=np.uint8)])
+
+
+@pytest.mark.parametrize("families,n", [
+    ([(300, 9_000, 0.01)], 4_000_000),                                  # groups of ~6 000 records: one workgroup each
+    ([(300, 9_000, 0.01), (60, 30_000, 0.002)], 5_000_000),            # ... and groups of ~22 000 among them: side by side
+    ([(150, 2_000, 0.02), (400, 900, 0.0), (40, 60_000, 0.0)], 4_000_000),   # small windows, an exact family, one of 60 000 copies
+])
+def test_high_copy_families_sort_their_groups_in_place(ctx, oracle, families, n):
+    """Re-keying levels sort every group where it lies (k_group_sort_small / _big, k_large_*): families of thousands of
+    near-identical copies give tie groups of every size class in the same level -- windows of small groups, groups above
+    4 096 records, groups above 16 384 records next to them."""
+    raw = _families_text(5, n, families)
+    b = assert_matches_oracle(ctx, oracle, raw)
+    assert b.stats.num_levels >= 3 and b.stats.deep_records > 1_000_000
+
+
 def test_protein_alphabet(ctx, oracle):
     d = sufr_amd.read_sequence_file(GOLDEN / "inputs" / "uniprot.fa")
     assert_matches_oracle(ctx, oracle, np.frombuffer(d.seq, dtype=np.uint8), is_dna=False)
