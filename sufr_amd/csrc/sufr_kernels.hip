@@ -1787,37 +1787,66 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
 // record t = rec_off[w] + (members below the slot) takes the written-back suffix of slot base + slot, its
 // segment is run_off[w] + (run heads at or below the slot) - 1, its output position is the slot itself;
 // every segment is re-keyed `depth0` characters in (the whole plain key matched).
+// DENSE = false: one thread per window walks its members (a window holds a couple of tied records on average: 3 per
+// window on the soft-mask-ignored human stand-in, where one wave per window costs 2.5 x as much).  DENSE = true: one wave
+// per window, lane l takes slots l and 64 + l -- the members' ordinals are popcounts of the masks below the lane, so the
+// suffixes are read and the records written side by side (22 tied records per window with the repeats indexed: the
+// thread-per-window walk, every load and store its own sector, took 16.7 ms for 502 M records).
+template <bool DENSE>
 __global__ void __launch_bounds__(256)
 k_build_ties(const unsigned long long* __restrict__ wmask, const uint32_t* __restrict__ rec_off,
              const uint32_t* __restrict__ run_off, const uint32_t* __restrict__ idxs, uint32_t m,
              uint32_t depth0, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
              uint32_t* __restrict__ opos_new, uint32_t* __restrict__ newdepth, uint8_t* __restrict__ newperiod)
 {
-    // one thread per window: a window holds only a couple of tied records on average
-    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t w = DENSE ? (blockIdx.x * 256 + threadIdx.x) >> 6 : blockIdx.x * 256 + threadIdx.x;
     const uint64_t base64 = (uint64_t)w * 128;
     if (base64 >= m) return;
     const uint32_t base = (uint32_t)base64;
-    uint64_t M[2] = {wmask[(size_t)w * 4 + 0], wmask[(size_t)w * 4 + 1]};
-    uint64_t H[2] = {wmask[(size_t)w * 4 + 2], wmask[(size_t)w * 4 + 3]};
-    if ((M[0] | M[1]) == 0ull) return;
-    uint32_t t = rec_off[w];
-    uint32_t sgm = run_off[w] - 1u;          // incremented at every run head
-    for (int half = 0; half < 2; half++) {
-        uint64_t mm = M[half];
-        while (mm) {
-            const int bit = __builtin_ctzll(mm);
-            mm &= mm - 1;
-            const uint32_t slot = (uint32_t)(half * 64 + bit);
-            if ((H[half] >> bit) & 1ull) {
-                sgm++;
-                newdepth[sgm] = depth0;
-                newperiod[sgm] = 1;
+    const ulonglong2 mm = *reinterpret_cast<const ulonglong2*>(wmask + (size_t)w * 4);
+    if ((mm.x | mm.y) == 0ull) return;
+    const ulonglong2 hh = *reinterpret_cast<const ulonglong2*>(wmask + (size_t)w * 4 + 2);
+    const uint32_t t0 = rec_off[w];
+    const uint32_t s0 = run_off[w] - 1u;          // + run heads at or below the slot
+    if (DENSE) {
+        const uint64_t M0 = mm.x, M1 = mm.y, H0 = hh.x, H1 = hh.y;
+        const uint32_t ln = lane_id();
+        const uint64_t lt = (1ull << ln) - 1ull, le = lt | (1ull << ln);
+        if ((M0 >> ln) & 1ull) {
+            const uint32_t t = t0 + (uint32_t)__popcll(M0 & lt);
+            const uint32_t g = s0 + (uint32_t)__popcll(H0 & le);
+            idx_new[t] = idxs[base + ln];
+            seg_new[t] = g;
+            opos_new[t] = base + ln;
+            if ((H0 >> ln) & 1ull) { newdepth[g] = depth0; newperiod[g] = 1; }
+        }
+        if ((M1 >> ln) & 1ull) {
+            const uint32_t t = t0 + (uint32_t)(__popcll(M0) + __popcll(M1 & lt));
+            const uint32_t g = s0 + (uint32_t)(__popcll(H0) + __popcll(H1 & le));
+            idx_new[t] = idxs[base + 64u + ln];
+            seg_new[t] = g;
+            opos_new[t] = base + 64u + ln;
+            if ((H1 >> ln) & 1ull) { newdepth[g] = depth0; newperiod[g] = 1; }
+        }
+    } else {
+        const uint64_t M[2] = {mm.x, mm.y}, H[2] = {hh.x, hh.y};
+        uint32_t t = t0, sgm = s0;               // incremented at every run head
+        for (int half = 0; half < 2; half++) {
+            uint64_t left = M[half];
+            while (left) {
+                const int bit = __builtin_ctzll(left);
+                left &= left - 1;
+                const uint32_t slot = (uint32_t)(half * 64 + bit);
+                if ((H[half] >> bit) & 1ull) {
+                    sgm++;
+                    newdepth[sgm] = depth0;
+                    newperiod[sgm] = 1;
+                }
+                idx_new[t] = idxs[base + slot];
+                seg_new[t] = sgm;
+                opos_new[t] = base + slot;
+                t++;
             }
-            idx_new[t] = idxs[base + slot];
-            seg_new[t] = sgm;
-            opos_new[t] = base + slot;
-            t++;
         }
     }
 }
@@ -1915,9 +1944,23 @@ k_build_level(const uint32_t* __restrict__ idx, uint32_t istride, const uint32_t
               uint32_t m_new, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
               uint32_t* __restrict__ opos_new)
 {
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    // the 256 slots of a workgroup lie in a handful of consecutive groups: two lanes bracket them over the whole table
+    // (19 dependent probes at 4 * 10^5 groups), the others search the bracket
+    __shared__ uint32_t s_br[2];
+    const uint32_t tb = blockIdx.x * 256;
+    if (threadIdx.x < 2) {
+        const uint32_t q = threadIdx.x == 0 ? tb : min(tb + 255u, m_new - 1u);
+        uint32_t a = 0, b = L;   // last k with start[k] <= q
+        while (b - a > 1) {
+            const uint32_t mid = a + (b - a) / 2;
+            if (start[mid] <= q) a = mid; else b = mid;
+        }
+        s_br[threadIdx.x] = a;
+    }
+    __syncthreads();
+    uint32_t t = tb + threadIdx.x;
     if (t >= m_new) return;
-    uint32_t lo = 0, hi = L;   // last k with start[k] <= t
+    uint32_t lo = s_br[0], hi = s_br[1] + 1u;   // last k with start[k] <= t
     while (hi - lo > 1) {
         uint32_t mid = lo + (hi - lo) / 2;
         if (start[mid] <= t) lo = mid; else hi = mid;
