@@ -2223,6 +2223,37 @@ k_mask_keys(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __rest
     key[j] = k;
 }
 
+// The same through LDS: the first `span` symbols of the suffix arrive eight bytes per load (the workspace copy of the
+// text is padded) and the care symbols are picked out of the thread's own row -- one visit of the text per suffix
+// instead of one byte load per care symbol, each of them 64 sectors at random per wave instruction.
+__global__ void __launch_bounds__(256)
+k_mask_keys_staged(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
+                   const uint32_t* __restrict__ idx, uint32_t m, const uint32_t* __restrict__ offs, int cnt, int b,
+                   uint32_t span, uint64_t* __restrict__ key)
+{
+    extern __shared__ __align__(16) uint8_t s_rows[];      // 256 rows of `pitch` bytes
+    __shared__ uint32_t s_offs[64];
+    __shared__ uint16_t s_lut[256];
+    const uint32_t words = (span + 7u) / 8u, pitch = words * 8u;
+    if ((int)threadIdx.x < cnt) s_offs[threadIdx.x] = offs[threadIdx.x];
+    s_lut[threadIdx.x] = glut[threadIdx.x];
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t p = idx[j];
+    uint64_t* me64 = reinterpret_cast<uint64_t*>(s_rows + (size_t)threadIdx.x * pitch);
+    const uint32_t w0 = s_offs[0] / 8u;                     // (the words this block of care offsets touches)
+    for (uint32_t w = w0; w <= s_offs[cnt - 1] / 8u; w++) me64[w] = load_u64_unaligned(text + p + 8u * w);
+    const uint8_t* me = reinterpret_cast<const uint8_t*>(me64);
+    uint64_t k = 0;
+    for (int c = 0; c < cnt; c++) {
+        const uint32_t o = s_offs[c];
+        const uint64_t code = p + o < n ? (uint64_t)(s_lut[me[o]] & 0x3ffu) : 0ull;
+        k |= code << (64 - b * (c + 1));
+    }
+    key[j] = k;
+}
+
 // LCP of the mask arm of find_lcp (272-300): equal care characters while both sides are inside the text
 __global__ void __launch_bounds__(256)
 k_mask_lcp(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t s,
@@ -2238,6 +2269,46 @@ k_mask_lcp(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
             if (qa >= n || qb >= n || text[qa] != text[qb]) break;
             c++;
         }
+    }
+    lcp[r] = c;
+}
+
+// The same with one visit of the text per rank: a workgroup stages the first `span` symbols (the reach of the mask) of
+// its 256 suffixes and of the one ranked before them in LDS, eight bytes per load (the workspace copy of the text is
+// padded), and every rank compares the care symbols with its neighbour's row there.
+// (k_mask_lcp reads both suffixes of every pair, two sectors at random per rank, byte by byte: 298 ms of the 440 ms of
+// the `hu-mask` build of the human-sized text, where weight 11 ties almost every neighbouring pair.)
+static constexpr int MASK_SPAN_MAX = 64;     // symbols per row of the staged version
+__global__ void __launch_bounds__(256)
+k_mask_lcp_staged(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ sa, uint32_t s,
+                  const uint32_t* __restrict__ offs, uint32_t weight, uint32_t span, uint32_t* __restrict__ lcp)
+{
+    extern __shared__ __align__(16) uint8_t s_rows[];      // (256 + 1) rows of `pitch` bytes; row 0 = the rank before
+    __shared__ uint32_t s_offs[MASK_SPAN_MAX];
+    __shared__ uint8_t s_in[260];                          // care symbols of the row inside the text (the offsets ascend)
+    const uint32_t words = (span + 7u) / 8u, pitch = words * 8u;
+    if (threadIdx.x < weight) s_offs[threadIdx.x] = offs[threadIdx.x];
+    __syncthreads();
+    const uint32_t r0 = blockIdx.x * 256;
+    for (uint32_t row = threadIdx.x; row < 257u; row += 256u) {
+        const uint64_t r = (uint64_t)r0 + row;              // rank r0 - 1 + row
+        if (r == 0 || r - 1 >= s) continue;
+        const uint64_t p = sa[r - 1];
+        uint64_t* me = reinterpret_cast<uint64_t*>(s_rows + (size_t)row * pitch);
+        for (uint32_t w = 0; w < words; w++) me[w] = load_u64_unaligned(text + p + 8u * w);
+        uint32_t in = 0;
+        while (in < weight && p + s_offs[in] < n) in++;
+        s_in[row] = (uint8_t)in;
+    }
+    __syncthreads();
+    const uint32_t r = r0 + threadIdx.x;
+    if (r >= s) return;
+    uint32_t c = 0;
+    if (r > 0) {
+        const uint8_t* a = s_rows + (size_t)threadIdx.x * pitch;
+        const uint8_t* b = a + pitch;
+        const uint32_t lim = min((uint32_t)s_in[threadIdx.x], (uint32_t)s_in[threadIdx.x + 1]);
+        while (c < lim && a[s_offs[c]] == b[s_offs[c]]) c++;
     }
     lcp[r] = c;
 }
