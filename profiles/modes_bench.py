@@ -1,6 +1,6 @@
 """Device time of the reference authors' other large builds (reference Makefile:67-83): `--dna -s 111010010100110111`
 on the 3.1 Gb human stand-in, `--dna -m 12` on the 100 Mb C. elegans stand-in, `--dna -m 16` on the 4.6 Mb E. coli
-stand-in (second build on a warm context):   python profiles/modes_bench.py"""
+stand-in (second build on a warm context):   python profiles/modes_bench.py [substring of the case names to run]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,10 @@ CASES = [
     ("ecoli -m 16", synth.syn_ecoli, 4_641_652, 1, dict(is_dna=True, max_query_len=16)),
     ("ecoli --dna", synth.syn_ecoli, 4_641_652, 1, dict(is_dna=True)),
 ]
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, gen, bases, seed, flags in CASES:
+    if ONLY not in name:
+        continue
     x, _ = gen(bases, seed=seed, device="cuda")
     db = sufr_amd.DeviceBuilder(0)
     out_sa = torch.empty(x.numel(), dtype=torch.int32, device="cuda")
