@@ -1,7 +1,8 @@
 """A soak of the whole library against the CPU checker with fresh seeds:   python profiles/soak.py [minutes] [seed]
 A third argument "big" restricts the loop to structured texts of 1 - 6 Mb.  Loops until the time is up over (1) small random texts (tests/test_gpu_parity.py::_fuzz_text) and structured 20 k - 400 k
 texts through the host ABI, (2) the same texts in forced windows, (3) the device search of the result against the host
-search of the written file.  Prints one line per failure and a summary; exit code 1 when anything differed.
+search of the written file, (4) --seed-mask builds against the checker and --max-query-len builds against min(LCP, L) and
+the descending-position rule, each in one window and in forced windows.  Prints one line per failure and a summary; exit code 1 when anything differed.
 (Test-side tooling: it imports the checker from tests/, like the tests do.)"""
 import os
 import sys
@@ -24,7 +25,7 @@ oracle = Oracle()
 ctx = sufr_amd.Context(0)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 fails = 0
-cases = {"host": 0, "windows": 0, "search": 0}
+cases = {"host": 0, "windows": 0, "search": 0, "options": 0}
 
 
 def structured(rng):
@@ -120,6 +121,45 @@ while time.time() < t_end:
                 report("windowed build", ctxt + f" window={window} margin={margin} width={width}", "arrays differ")
         except Exception as e:
             report("windowed build", ctxt + f" window={window} margin={margin} width={width}", repr(e))
+        ctx.set_window(0, 0)
+    # (4) --seed-mask / --max-query-len, one window and forced windows
+    if it % 5 == 0 and raw.size > 64 and norm.size >= 4:
+        try:
+            window = int(rng.integers(max(16, raw.size // 15 + 1), raw.size)); margin = int(rng.choice([16, 64, 1000]))
+            width = int(rng.choice([4, 8]))
+            if rng.random() < 0.5:
+                mask = "1" + "".join(rng.choice(["0", "1"], size=int(rng.integers(1, 20)))) + "1"
+                if "0" not in mask:
+                    mask = "10" + mask                    # (the reference rejects masks without a 0, types.rs:36-200)
+                try:
+                    msa, mlcp, _ = oracle.build(norm, is_dna=is_dna, allow_ambiguity=amb, seed_mask=mask, threads=8)
+                except RuntimeError:                      # inputs the reference itself cannot build (pivot hazards)
+                    continue
+                for w in ((0, 0), (window, margin)):
+                    ctx.set_window(*w)
+                    b = sufr_amd.SufrBuilder(sufr_amd.SufrBuilderArgs(text=raw, is_dna=is_dna, allow_ambiguity=amb, ignore_softmask=soft,
+                                                                      seed_mask=mask), index_width=width, ctx=ctx, write=False)
+                    if not (np.array_equal(b.suffix_array.astype(np.uint64), msa.astype(np.uint64)) and
+                            np.array_equal(b.lcp.astype(np.uint64), mlcp.astype(np.uint64))):
+                        report("seed-mask build", ctxt + f" mask={mask} window={w} width={width}", "arrays differ")
+            else:
+                L = int(rng.choice([1, 2, 5, 12, 21, 22, 40, 300]))
+                got = []
+                for w in ((0, 0), (window, margin)):
+                    ctx.set_window(*w)
+                    b = sufr_amd.SufrBuilder(sufr_amd.SufrBuilderArgs(text=raw, is_dna=is_dna, allow_ambiguity=amb, ignore_softmask=soft,
+                                                                      max_query_len=L), index_width=width, ctx=ctx, write=False)
+                    got.append((b.suffix_array.astype(np.int64), b.lcp.astype(np.uint64)))
+                sa1, lcp1 = got[0]
+                tie = lcp1 >= L
+                if not (np.array_equal(lcp1, np.minimum(want_lcp, L)) and np.array_equal(np.sort(sa1), np.sort(want_sa.astype(np.int64)))
+                        and bool(np.all(sa1[1:][tie[1:]] < sa1[:-1][tie[1:]]))):
+                    report("max-query-len build", ctxt + f" L={L}", "not the canonical form")
+                if not (np.array_equal(got[1][0], sa1) and np.array_equal(got[1][1], lcp1)):
+                    report("max-query-len build", ctxt + f" L={L} window={window} margin={margin} width={width}", "windows differ from one window")
+            cases["options"] += 1
+        except Exception as e:
+            report("option build", ctxt, repr(e))
         ctx.set_window(0, 0)
     # (3) device search against the host search of the written file
     if it % 4 == 0 and want_sa.size > 8:
