@@ -28,6 +28,20 @@
 #include "sufr_runkey.h"
 
 namespace sufr {
+// phase stamps (probes build): cycles per phase of the last wave of every workgroup, summed; printed with SUFR_HIP_DEBUG=1
+#ifdef SUFR_HIP_PROBES
+__device__ unsigned long long g_phase[3][16];          // cycles per phase, summed over workgroups: part, scatter, k_finish<DEEP>
+#define SUFR_STAMP(acc, i) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); acc[i] += t__ - stamp__; stamp__ = t__; }
+#define SUFR_STAMP_DECL(n) unsigned long long ph__[n] = {}; unsigned long long stamp__ = __builtin_amdgcn_s_memtime();
+#define SUFR_STAMP_FLUSH(k, n) if ((threadIdx.x & 63u) == 0 && (threadIdx.x >> 6) == gridDim.y * 0 + (blockDim.x >> 6) - 1) { for (int i__ = 0; i__ < n; i__++) atomicAdd(&g_phase[k][i__], ph__[i__]); }
+#else
+#define SUFR_STAMP(acc, i)
+#define SUFR_STAMP_DECL(n)
+#define SUFR_STAMP_FLUSH(k, n)
+#endif
+}  // namespace sufr
+
+namespace sufr {
 
 static constexpr int WAVE = 64;
 static_assert(RUN_TILE == (uint32_t)TILE, "run-end table granularity");
@@ -1498,7 +1512,7 @@ __device__ __forceinline__ uint32_t walk_key_common(uint64_t a, uint64_t b)
 // stay flagged for the next level (without this pass a straddling small group would be deferred level
 // after level: one in five straddles again after repacking).
 template <bool DEEP, bool TIES_OUT, bool CROSS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)       // 5 waves per SIMD (96 registers, no spill): the rounds are chains of random reads
 k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
          const uint32_t* __restrict__ segdepth, uint32_t m,
@@ -1612,7 +1626,12 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     uint32_t extra0 = 0, extra1 = 0;          // characters a capped pair walk has matched beyond the key
     const uint64_t max_round = n + 8;        // distinct suffixes separate within n characters
     bool lt0 = false, lt1 = false;           // tie flags of the last ranking
+    SUFR_STAMP_DECL(8)
     for (uint64_t round = 0; __ballot(act0 || act1) != 0ull && round < max_round; round++) {
+        SUFR_STAMP(ph__, 0)
+#ifdef SUFR_HIP_PROBES
+        ph__[5] += 1000;                      // (rounds, in thousands of a 'cycle')
+#endif
         // ---- rank every active record inside its group (counting sort through LDS) ----------------
         sk[ln] = k0; sk[64 + ln] = k1; sg[ln] = gid0; sg[64 + ln] = gid1;
         uint32_t np0 = (uint32_t)ln, np1 = (uint32_t)(64 + ln);
@@ -1662,6 +1681,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         gid1 = act1 ? (uint32_t)ng1 : (0x10000u | (uint32_t)(64 + ln));
         lt0 = tie0; lt1 = tie1;
         if (TIES_OUT) break;                  // tie runs go to the dense tie level (k_build_ties)
+        SUFR_STAMP(ph__, 1)
         // ---- pairs: two suffixes that still tie (and nobody else with them) are compared directly, eight
         // characters per step, instead of being re-keyed ~20 characters per round: an exact duplicate of 100 kb is
         // 10^5 such pairs with common prefixes of up to 10^5 characters (find_lcp's byte walk, sufr_builder.rs:
@@ -1711,6 +1731,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
                 }
             }
         }
+        SUFR_STAMP(ph__, 2)
         // ---- still tied: the whole key matched; re-key where the common prefix now ends -------------
         // Run keys and walk keys take turns: a run key looks ~20 characters ahead (or across a whole run); if that
         // did not part the group, its members are copies of something long -- the next key is the common prefix with
@@ -1748,7 +1769,9 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
             }
             ktype = 1;
         }
+        SUFR_STAMP(ph__, 3)
     }
+    SUFR_STAMP(ph__, 0)
     if (TIES_OUT) {
         // describe this window's tie runs: members (M) and run heads (H); write the members back in order
         const uint64_t M0 = __ballot(act0), M1 = __ballot(act1);
@@ -1781,6 +1804,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         if ((!tied || !lt1) && !first1) LCP[o] = lcp1;
     }
     if (CROSS && ln == 0) wl_flag[wave] = 0u;       // finished here
+    SUFR_STAMP(ph__, 4)
+    if (DEEP && !TIES_OUT) { SUFR_STAMP_FLUSH(2, 8) }
 }
 
 // Dense level out of the tie runs that k_finish<false, true> described per window:
