@@ -101,7 +101,10 @@ int  sufr_hip_synchronize(sufr_hip_ctx *ctx);
 /* Texts of 2^32 - 2^24 bytes and more (the u64 arm of SuffixArray::write, suffix_array.rs:460-470) are built in
  * overlapping 32-bit windows that are merged by rank on the device (sufr_wide.inc).  window: positions per window,
  * margin: comparison context after them; 0, 0 selects the defaults (as few windows as fit, 2^26).  A non-zero window
- * also sends shorter texts of more than `window` bytes down the same path (memory-bound callers; the tests). */
+ * also sends shorter texts of more than `window` bytes down the same path (memory-bound callers; the tests).
+ * max_query_len / seed_mask builds take the same windows (built with the option, merged under its order).  A repeat
+ * that crosses the end of a window and is longer than the widest margin 32 bits allow (~2^31 symbols) is the one
+ * input the windowed build returns SUFR_HIP_E_UNSUPPORTED for. */
 int  sufr_hip_set_window(sufr_hip_ctx *ctx, uint64_t window, uint64_t margin);
 
 /* ---- text normalisation: sufr_builder.rs:144-160 (host helper; the GPU build can also do it) --- */
@@ -131,8 +134,8 @@ int sufr_hip_sort_device_u32(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, 
                              void *d_sa, void *d_lcp, uint64_t cap,
                              uint64_t *num_suffixes_out, sufr_hip_stats *stats);
 /* u64-index twin (SufrBuilder<u64>; suffix_array.rs:461 selects it when n >= u32::MAX).  Texts below
- * 2^32 - 2^24 bytes are built with 32-bit indices on the device and widened; longer texts return
- * SUFR_HIP_E_UNSUPPORTED for now (the u32 entry points have the same limit). */
+ * 2^32 - 2^24 bytes are built with 32-bit indices on the device and widened; longer texts take the windowed build
+ * (sufr_hip_set_window above; single-shard: num_shards > 1 returns SUFR_HIP_E_UNSUPPORTED for them). */
 int sufr_hip_sort_device_u64(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,
                              uint64_t max_query_len, const char *seed_mask,
                              uint64_t num_partitions, uint64_t random_seed,
