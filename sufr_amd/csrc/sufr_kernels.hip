@@ -1541,8 +1541,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     // set to 1 while the group stays large and to 0 once it has been finished here)
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     if (CROSS ? (wave >= ncross) : ((uint64_t)wave * 128 >= m)) return;
-    const uint64_t base64 = CROSS ? (uint64_t)wl_head[wave] : (uint64_t)wave * 128;
-    const uint32_t base = (uint32_t)base64;
+    uint64_t base64 = CROSS ? (uint64_t)wl_head[wave] : (uint64_t)wave * 128;
     if (CROSS && (threadIdx.x & 63u) == 0) wl_flag[wave] = 1u;
     const int wv = threadIdx.x >> 6;
     auto sk = SUFR_LDS_VOLATILE(uint64_t, sh_key[wv]);
@@ -1551,6 +1550,36 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     const int ln = (int)lane_id();
     const bool whole = sorted_bits == 0;            // groups are whole segments (no key bits sorted yet)
     const int group_shift = whole ? 0 : 64 - sorted_bits;
+    // A wave owns the groups that START in its 128 records.  It works on the 128 records from its first group head on:
+    // what it skips at the front belongs to the wave before, and the group that ran past its end now does so only if it
+    // overhangs by more than that (a level of tie runs of ~12 records: half the windows flagged a crossing group for the
+    // second pass when every wave sat on its own 128 records).
+    uint32_t own_limit = 128u;                      // groups whose head slot is below this are this wave's
+    if (DEEP && !TIES_OUT && !CROSS) {
+        const uint32_t b0 = (uint32_t)base64;
+        const uint32_t a0 = b0 + (uint32_t)ln, a1 = b0 + 64u + (uint32_t)ln;
+        const bool v0 = a0 < m, v1 = a1 < m;
+        const uint64_t pk0 = v0 ? keys[a0] : ~0ull, pk1 = v1 ? keys[a1] : ~0ull;
+        const uint32_t ps_0 = v0 ? segs[a0] : 0xffffffffu, ps_1 = v1 ? segs[a1] : 0xffffffffu;
+        uint64_t q0 = shfl64_up1(pk0), q1 = shfl64_up1(pk1);
+        uint32_t r0 = __shfl_up(ps_0, 1, WAVE), r1 = __shfl_up(ps_1, 1, WAVE);
+        const uint64_t l0k = shfl64(pk0, 63); const uint32_t l0s = __shfl(ps_0, 63, WAVE);
+        if (ln == 0) {
+            q1 = l0k; r1 = l0s;
+            if (b0 > 0) { q0 = keys[b0 - 1]; r0 = segs[b0 - 1]; }
+        }
+        const bool e0 = !v0 || (ln == 0 && b0 == 0) || r0 != ps_0 || (!whole && (q0 >> group_shift) != (pk0 >> group_shift));
+        const bool e1 = !v1 || r1 != ps_1 || (!whole && (q1 >> group_shift) != (pk1 >> group_shift));
+        const uint64_t E0 = __ballot(e0), E1 = __ballot(e1);
+        const uint32_t first = E0 ? (uint32_t)__builtin_ctzll(E0) : (E1 ? 64u + (uint32_t)__builtin_ctzll(E1) : 128u);
+        if (first >= 128u || (uint64_t)b0 + first >= m) {       // no group starts here: nothing to own
+            if (ln == 0) wl_flag[wave] = 0u;
+            return;
+        }
+        base64 += first;
+        own_limit = 128u - first;
+    }
+    const uint32_t base = (uint32_t)base64;
     const uint32_t j0 = base + ln, j1 = base + 64 + ln;
     const bool in0 = j0 < m, in1 = j1 < m;
 
@@ -1595,7 +1624,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     const int none = h128 ? 128 : 1000;
     const int nx0 = mask_next_set(H0, H1, ln, none), nx1 = mask_next_set(H0, H1, 64 + ln, none);
     // group starts inside this window (CROSS: only the flagged group, whose head is slot 0)
-    const bool own0 = in0 && (CROSS ? g0 == 0 : g0 >= 0), own1 = in1 && (CROSS ? g1 == 0 : g1 >= 0);
+    const bool own0 = in0 && (CROSS ? g0 == 0 : (g0 >= 0 && (uint32_t)g0 < own_limit));
+    const bool own1 = in1 && (CROSS ? g1 == 0 : (g1 >= 0 && (uint32_t)g1 < own_limit));
     const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
     // Only the window's last group can run past its end, so a window reports at most one large group:
     // a flag and a head position per window, compacted afterwards by a scan (k_compact_large).  (Appending
