@@ -13,10 +13,12 @@ text, _ = synth.syn_human(n, seed=4, device="cuda")
 out_sa = torch.empty(text.numel(), dtype=torch.int32, device="cuda")
 out_lcp = torch.empty(text.numel(), dtype=torch.int32, device="cuda")
 db = sufr_amd.DeviceBuilder(0)
-for shards in (1, 2, 4, 8):
+SHARDS = tuple(int(x) for x in os.environ.get("SUFR_SHARDS", "1,2,4,8").split(","))
+ENDS_ONLY = bool(os.environ.get("SUFR_SHARD_ENDS"))     # time only the first and the last rank of every split
+for shards in SHARDS:
     worst = 0.0
-    for r in range(shards):
-        for rep in range(2):
+    for r in (sorted({0, shards - 1}) if ENDS_ONLY else range(shards)):
+        for rep in range(int(os.environ.get("SUFR_SHARD_REPS", "2"))):
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); ev0.record()
             db.sort(text, is_dna=True, ignore_softmask=True, raw_text=True, out_sa=out_sa, out_lcp=out_lcp,
