@@ -90,6 +90,11 @@ int  sufr_hip_index_load(sufr_hip_ctx *ctx, const sufr_file *f, sufr_hip_index *
 int  sufr_hip_index_wrap(sufr_hip_ctx *ctx, const void *d_text, uint64_t text_len, const void *d_sa, uint64_t num_suffixes,
                          uint32_t flags, uint64_t built_max_query_len, const char *seed_mask, sufr_hip_index **out);
 void sufr_hip_index_free(sufr_hip_index *ix);
+/* Bytes per entry of the index's suffix array, 4 or 8: the width sufr_hip_index_wrap assumed for d_sa (8 iff text_len >=
+ * 2^32 - 1 or SUFR_HIP_FLAG_SA_U64) and the width of the d_positions entries of sufr_hip_locate_batch_device, whose `cap` is
+ * counted in entries of that width.  sufr_hip_index_wrap refuses a d_sa whose device allocation is shorter than
+ * num_suffixes entries of it (SUFR_HIP_E_INVALID). */
+int  sufr_hip_index_width(const sufr_hip_index *ix);
 int  sufr_hip_search_batch(sufr_hip_ctx *ctx, const sufr_hip_index *ix, const uint8_t *queries, const uint64_t *offsets,
                            uint64_t num_queries, int has_max_query_len, uint64_t max_query_len, uint64_t *rank_lo,
                            uint64_t *rank_hi);

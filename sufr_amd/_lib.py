@@ -81,7 +81,7 @@ QUERY_EXPORTS = [
     "sufr_file_open", "sufr_file_close", "sufr_file_metadata", "sufr_file_text", "sufr_file_seed_mask",
     "sufr_file_suffix_array", "sufr_file_lcp_array", "sufr_file_suffix", "sufr_file_lcp", "sufr_file_sequence_start",
     "sufr_file_sequence_name", "sufr_file_sequence_of", "sufr_file_search", "sufr_file_search_batch",
-    "sufr_hip_index_load", "sufr_hip_index_wrap", "sufr_hip_index_free", "sufr_hip_search_batch",
+    "sufr_hip_index_load", "sufr_hip_index_wrap", "sufr_hip_index_free", "sufr_hip_index_width", "sufr_hip_search_batch",
     "sufr_hip_search_batch_device", "sufr_hip_locate_batch_device",
 ]
 
@@ -183,6 +183,7 @@ def lib() -> C.CDLL:
     L.sufr_hip_index_load.argtypes = [vp, vp, C.POINTER(vp)]; L.sufr_hip_index_load.restype = C.c_int
     L.sufr_hip_index_wrap.argtypes = [vp, vp, u64, vp, u64, u32, u64, cp, C.POINTER(vp)]; L.sufr_hip_index_wrap.restype = C.c_int
     L.sufr_hip_index_free.argtypes = [vp]; L.sufr_hip_index_free.restype = None
+    L.sufr_hip_index_width.argtypes = [vp]; L.sufr_hip_index_width.restype = C.c_int
     L.sufr_hip_search_batch.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]; L.sufr_hip_search_batch.restype = C.c_int
     L.sufr_hip_search_batch_device.argtypes = [vp, vp, vp, vp, u64, C.c_int, u64, vp, vp]
     L.sufr_hip_search_batch_device.restype = C.c_int

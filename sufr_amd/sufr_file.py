@@ -90,6 +90,10 @@ class SufrFile:
         rc = L.sufr_file_open(str(filename).encode(), C.byref(h), err, len(err))
         if rc != 0:
             raise SufrHipError(rc, err.value.decode())
+        import threading
+        self._view_lock = threading.Lock()
+        self._live_views = 0
+        self._close_pending = False
         self._h = h
         self.filename = str(filename)
         m = FileMeta()
@@ -107,46 +111,74 @@ class SufrFile:
             self.seed_mask = "".join("1" if b == 1 else "0" for b in raw)
 
     # -- views into the mapping --------------------------------------------------------------------------------------
-    # Zero-copy: the arrays alias the mapped file.  Every view keeps the mapping alive -- it holds a reference to this
-    # object (so `SufrFile(p).suffix_array.tolist()` works), and close() / __del__ only unmap once the last view is
-    # gone (a close() with views outstanding is deferred to the last view's finaliser).
-    def _view(self, ptr, count, dtype):
-        if count == 0:
-            return np.empty(0, dtype=dtype)
+    # Zero-copy: the arrays alias the mapped file, and every view PINS the mapping -- it holds a reference to this
+    # object (so `SufrFile(p).suffix_array.tolist()` works).  close() (and leaving a `with` block) is therefore a
+    # REQUEST while views are alive: the file stays mapped and open until the last view is gone (`pending_close` is
+    # True meanwhile, `closed` only afterwards).  A caller that must release the file at a known point -- before
+    # re-creating or truncating the same path, which would turn reads of a stale view into SIGBUS -- drops its views
+    # first or takes copies (`copy=True` of array()).  The view count is guarded by a lock: finalisers run on
+    # whichever thread drops the last reference.
+    def _view(self, getter, count, dtype):
         import weakref
-        buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        with self._view_lock:
+            if self._h is None:
+                raise ValueError("SufrFile is closed")
+            if count == 0:
+                return np.empty(0, dtype=dtype)
+            buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(getter(self._h))
+            self._live_views += 1
         buf._owner = self
         arr = np.frombuffer(buf, dtype=dtype)
-        self._live_views = getattr(self, "_live_views", 0) + 1
         weakref.finalize(buf, SufrFile._view_gone, self)
         return arr
 
     @staticmethod
     def _view_gone(owner):
-        owner._live_views -= 1
-        if owner._live_views == 0 and getattr(owner, "_close_pending", False):
-            owner._close_pending = False
+        with owner._view_lock:
+            owner._live_views -= 1
+            last = owner._live_views == 0 and owner._close_pending
+        if last:
             owner.close()
 
     @property
+    def closed(self) -> bool:
+        """The mapping is gone (no view outstanding, close() done)."""
+        return self._h is None
+
+    @property
+    def pending_close(self) -> bool:
+        """close() was called while views were alive: the file is unmapped when the last of them goes."""
+        return self._close_pending and self._h is not None
+
+    def array(self, which: str, copy: bool = False) -> np.ndarray:
+        """'text' | 'suffix_array' | 'lcp'; copy=True returns an array of its own (it does not pin the mapping)."""
+        a = {"text": lambda: self.text, "suffix_array": lambda: self.suffix_array, "lcp": lambda: self.lcp}[which]()
+        return a.copy() if copy else a
+
+    @property
     def text(self) -> np.ndarray:
-        return self._view(lib().sufr_file_text(self._h), self.text_len, np.uint8)
+        return self._view(lib().sufr_file_text, self.text_len, np.uint8)
 
     @property
     def suffix_array(self) -> np.ndarray:
-        return self._view(lib().sufr_file_suffix_array(self._h), self.len_suffixes, np.uint32 if self.index_width == 4 else np.uint64)
+        return self._view(lib().sufr_file_suffix_array, self.len_suffixes, np.uint32 if self.index_width == 4 else np.uint64)
 
     @property
     def lcp(self) -> np.ndarray:
-        return self._view(lib().sufr_file_lcp_array(self._h), self.len_suffixes, np.uint32 if self.index_width == 4 else np.uint64)
+        return self._view(lib().sufr_file_lcp_array, self.len_suffixes, np.uint32 if self.index_width == 4 else np.uint64)
 
     def close(self):
-        if getattr(self, "_live_views", 0) > 0:          # arrays still alias the mapping: unmap when the last one goes
-            self._close_pending = True
+        lock = getattr(self, "_view_lock", None)
+        if lock is None:                                  # (__init__ failed before the mapping existed)
             return
-        if getattr(self, "_h", None):
-            lib().sufr_file_close(self._h)
-            self._h = None
+        with lock:
+            if self._live_views > 0:                      # arrays still alias the mapping: unmap when the last one goes
+                self._close_pending = True
+                return
+            h, self._h = self._h, None
+            self._close_pending = False
+        if h:
+            lib().sufr_file_close(h)
 
     def __enter__(self):
         return self
@@ -284,7 +316,7 @@ class DeviceIndex:
         h = C.c_void_p()
         ctx.check(lib().sufr_hip_index_load(ctx.handle, f._h, C.byref(h)))
         ix = cls(ctx, h)
-        ix.index_width = f.index_width
+        ix.index_width = lib().sufr_hip_index_width(h)     # (= f.index_width: the file format's rule)
         return ix
 
     @classmethod
@@ -304,7 +336,8 @@ class DeviceIndex:
         ctx.check(lib().sufr_hip_index_wrap(ctx.handle, text.data_ptr(), text.numel(), sa.data_ptr(), sa.numel(), flags,
                                             max_query_len, seed_mask.encode() if seed_mask else None, C.byref(h)))
         ix = cls(ctx, h, keep=(text, sa))
-        ix.index_width = 8 if wide else 4
+        ix.index_width = lib().sufr_hip_index_width(h)     # 8 iff the array was taken as 64-bit
+        assert ix.index_width == (8 if wide else 4)
         return ix
 
     def close(self):

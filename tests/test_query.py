@@ -365,3 +365,23 @@ def test_malformed_files_are_refused(tmp_path):
     assert "corrupt" in opens(bytes(b))
     with pytest.raises(sufr_amd.SufrHipError):
         SufrFile(tmp_path / "missing.sufr")
+
+
+def test_views_pin_the_mapping_and_close_is_a_request_until_they_are_gone():
+    """SufrFile views alias the mapped file: close() with a view alive is deferred (pending_close), the file is unmapped
+    when the last view goes (closed); a copy does not pin anything; a closed file hands out no more views."""
+    import gc
+    with SufrFile(str(EXP / "1.sufr")) as f:
+        sa = f.suffix_array
+        kept = f.array("lcp", copy=True)
+    assert f.pending_close and not f.closed
+    assert sa.tolist() == parse_sufr(EXP / "1.sufr").sa.tolist()      # still readable: the mapping is alive
+    del sa
+    gc.collect()
+    assert f.closed and not f.pending_close
+    assert kept.tolist() == parse_sufr(EXP / "1.sufr").lcp.tolist()
+    with pytest.raises(ValueError):
+        f.suffix_array
+    g = SufrFile(str(EXP / "1.sufr"))
+    g.close()
+    assert g.closed
