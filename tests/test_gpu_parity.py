@@ -848,6 +848,42 @@ def test_human_prefix_400mb_section_hashes_equal_oracle(oracle):
     db.close()
 
 
+@pytest.mark.parametrize("mode", ["dna", "allow_ambiguity"])
+def test_human_prefix_400mb_deep_modes_section_hashes_equal_oracle(oracle, mode):
+    """The same 400 Mb prefix in the two modes that load the deep levels: `--dna` alone -- the soft-masked
+    repeat families are indexed: 25 levels, 60 % of the suffixes tie beyond the 21-character key -- and `--dna
+    --allow-ambiguity` (suffixes inside N runs indexed; the runs are broken below 1000, at random places, so that the
+    reference's N-run shortcut, sufr_builder.rs:302-307, never fires and the reference is deterministic).  xxh64 of the SA and of the LCP
+    section equal the oracle's."""
+    import xxhash
+    x, _ = synth.syn_human(3_100_000_000, seed=4, device="cuda")
+    x = x[:400_000_001].clone()
+    x[-1] = ord("$")
+    amb = mode == "allow_ambiguity"
+    if amb:
+        # breaks at random places with random bases (and every 900th position, so that no run reaches 1000): a regular
+        # N^899 A N^899 A ... would be a tandem array over megabases -- LCPs of 10^6 and more that the oracle's byte walk
+        # (find_lcp 319-329) does not survive
+        g = torch.Generator(device=x.device); g.manual_seed(5)
+        isn = (x == ord("N")) | (x == ord("n"))
+        brk = isn & ((torch.rand(x.numel(), generator=g, device=x.device) < 1 / 300) |
+                     (torch.arange(x.numel(), device=x.device) % 900 == 0))
+        bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=x.device)[
+            torch.randint(0, 4, (x.numel(),), generator=g, device=x.device)]
+        x[brk] = bases[brk]
+        del isn, brk, bases
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True, allow_ambiguity=amb, ignore_softmask=False, raw_text=True, num_partitions=256)
+    assert db.stats.num_levels > 8                       # the deep path ran
+    norm = oracle.normalize(x.cpu().numpy(), False)
+    osa, olcp, _ = oracle.build(norm, is_dna=True, allow_ambiguity=amb, num_partitions=256, threads=os.cpu_count() or 1)
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    assert gsa.size == osa.size
+    assert xxhash.xxh64(gsa.tobytes()).hexdigest() == xxhash.xxh64(osa.tobytes()).hexdigest()
+    assert xxhash.xxh64(glcp.tobytes()).hexdigest() == xxhash.xxh64(olcp.tobytes()).hexdigest()
+    db.close()
+
+
 def test_human_config_c4_properties():
     """BASELINE config C4 size (3.1 Gb stand-in, --dna --ignore-softmask): size-independent properties checked
     on the GPU itself (sufr_amd/verify.py) -- SA is a permutation of the eligible positions (count, sum, a
