@@ -18,6 +18,15 @@ if os.environ.get("SUFR_AMD_PROBES_LIB"):
     print(f"sufr_amd: SUFR_AMD_PROBES_LIB is set -- loading the PROBES build {LIB_PATH.name} (tuning knobs from "
           "SUFR_PROBE_*; for profiling only)", file=_sys.stderr)
 CLI_PATH = CSRC / "_build" / "sufr"
+# tests/test_sanitized_host.py runs the host-side tests in a child process against the HOST-ONLY AddressSanitizer + UBSan
+# build (`make asan`: reader, writer, query code; every device entry point answers "no device").  Loud, like the probes switch.
+HOST_ASAN = bool(os.environ.get("SUFR_AMD_HOST_ASAN_LIB"))
+if HOST_ASAN:
+    import sys as _sys
+    LIB_PATH = CSRC / "_build" / "libsufr_host_asan.so"
+    CLI_PATH = CSRC / "_build" / "sufr_host_asan"
+    print(f"sufr_amd: SUFR_AMD_HOST_ASAN_LIB is set -- loading the host-only sanitizer build {LIB_PATH.name} (no device code)",
+          file=_sys.stderr)
 
 
 class SufrHipError(RuntimeError):
@@ -100,7 +109,7 @@ _lib = None
 
 def build_extension(verbose: bool = False) -> Path:
     """Compile the HIP library and the CLI for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", str(CSRC)], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", str(CSRC)] + (["asan"] if HOST_ASAN else []), capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libsufr_hip.so failed:\n" + r.stdout + r.stderr)
     if verbose:
@@ -119,7 +128,7 @@ def lib() -> C.CDLL:
     # torch afterwards ends up with two runtimes, and the second one to initialise finds no device.  Whoever uses the
     # Python binding next to torch gets torch's runtime for both: import it first when it is installed.
     import sys
-    if "torch" not in sys.modules:
+    if "torch" not in sys.modules and not HOST_ASAN:
         try:
             import torch  # noqa: F401
         except ImportError:

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <memory>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -285,6 +286,7 @@ extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, 
                                         uint32_t num_shards, uint64_t* num_suffixes, sufr_hip_stats* stats,
                                         int* device, const void** d_text, const void** d_sa,
                                         const void** d_lcp);                               // sufr_capi.inc
+extern "C" void sufr_hip_release_build_arrays_(sufr_hip_ctx* ctx, int also_text);
 extern "C" int sufr_hip_resident_ends_(sufr_hip_ctx* ctx, uint64_t s, uint64_t* first, uint64_t* last);
 extern "C" int sufr_hip_resident_stitch_(sufr_hip_ctx* ctx, uint64_t n, uint64_t prev_last, uint64_t* lcp_out);
 extern "C" int sufr_hip_resident_arrays_(sufr_hip_ctx* ctx, int* device, const void** d_text, const void** d_sa,
@@ -336,28 +338,39 @@ int stream_sections(int device, int fd, const std::vector<Section>& secs)
     if (pieces.empty()) return 0;
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
-    unsigned W = host_threads(12);
+    // (buffered writes to ONE file are serialised by its inode lock: 9.9 GB/s on the test box with 1 or 8 writers, 71 GB/s into
+    // 8 files -- profiles/r04_pagecache_write.txt; a few double-buffered workers keep that one writer fed)
+    unsigned W = host_threads(4);
 #ifdef SUFR_HIP_PROBES
     if (const char* e = getenv("SUFR_PROBE_WRITE_THREADS")) if (atoi(e) > 0) W = (unsigned)atoi(e);
 #endif
     if (W > pieces.size()) W = (unsigned)pieces.size();
+    // a worker keeps two pinned buffers: the copy of its next piece runs while it writes the one before (round 3 copied,
+    // waited, wrote, one after the other: the page cache then saw ~10.6 of the 15 GB/s it takes from a hot buffer)
     auto worker = [&]() {
-        void* pin = nullptr;
+        void* pin[2] = {nullptr, nullptr};
         hipStream_t st = nullptr;
-        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin, PIECE, hipHostMallocDefault) != hipSuccess ||
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&pin[0], PIECE, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&pin[1], PIECE, hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
             failed = 1;
-            if (pin) (void)hipHostFree(pin);
+            for (void* q : pin) if (q) (void)hipHostFree(q);
             return;
         }
-        for (size_t i; !failed && (i = next.fetch_add(1)) < pieces.size();) {
-            const Piece& pc = pieces[i];
-            if (hipMemcpyAsync(pin, pc.src, pc.len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { failed = 1; break; }
-            if (!pwrite_all(fd, pin, pc.len, pc.off)) { failed = 2; break; }
+        size_t cur = next.fetch_add(1);
+        int b = 0;
+        if (cur < pieces.size() && hipMemcpyAsync(pin[0], pieces[cur].src, pieces[cur].len, hipMemcpyDeviceToHost, st) != hipSuccess) failed = 1;
+        while (!failed && cur < pieces.size()) {
+            if (hipStreamSynchronize(st) != hipSuccess) { failed = 1; break; }
+            const size_t nx = next.fetch_add(1);
+            if (nx < pieces.size() &&
+                hipMemcpyAsync(pin[b ^ 1], pieces[nx].src, pieces[nx].len, hipMemcpyDeviceToHost, st) != hipSuccess) { failed = 1; break; }
+            if (!pwrite_all(fd, pin[b], pieces[cur].len, pieces[cur].off)) { failed = 2; break; }
+            cur = nx; b ^= 1;
         }
+        (void)hipStreamSynchronize(st);
         (void)hipStreamDestroy(st);
-        (void)hipHostFree(pin);
+        for (void* q : pin) (void)hipHostFree(q);
     };
     std::vector<std::thread> th;
     for (unsigned w = 0; w < W; w++) th.emplace_back(worker);
@@ -535,8 +548,14 @@ int sufr_read_sequence_file(const char* path, uint8_t delimiter, sufr_sequence_d
     if (!fastq && T > 1 && (size_t)(end - p) >= ((size_t)32 << 20) && !getenv("SUFR_SERIAL_READER")) {
         std::vector<uint64_t> pstarts;
         std::vector<std::string> pnames;
-        uint8_t* buf = (uint8_t*)malloc((size_t)(end - p) + 2);
+        // (2 MB-aligned and advised for transparent huge pages: 3 GB of text in 4 KB pages is 760 000 page faults while
+        // the parser fills it and as many pages to hand back when the process ends -- 0.2 s of a 2.2 s `sufr create`)
+        const size_t bytes = (((size_t)(end - p) + 2) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        uint8_t* buf = (uint8_t*)aligned_alloc((size_t)2 << 20, bytes);
         if (!buf) { put_err(err, errlen, "out of memory"); return SUFR_HIP_E_NOMEM; }
+#ifdef MADV_HUGEPAGE
+        (void)madvise(buf, bytes, MADV_HUGEPAGE);
+#endif
         uint64_t len = 0;
         fasta_parallel(p, end, delimiter, T, buf, len, pstarts, pnames);
         buf[len++] = SUFR_SENTINEL_CHARACTER;                        // util.rs:83
@@ -707,7 +726,9 @@ int sufr_hip_shard_write(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const 
     if (write_text) secs.push_back({d_text, sd->seq_len, L.text_pos});
     secs.push_back({d_sa, num_suffixes * 4, L.sa_pos + suffix_offset * 4});
     secs.push_back({d_lcp, num_suffixes * 4, L.lcp_pos + suffix_offset * 4});
+    std::thread freer([ctx, write_text]() { sufr_hip_release_build_arrays_(ctx, !write_text); });     // (under the copies: not in the process's exit)
     int failed = stream_sections(device, fd, secs);
+    freer.join();
     if (close(fd) != 0 && !failed) failed = 2;
     if (failed) {
         sufr_hip_set_error_(ctx, failed == 2 ? (std::string(outfile) + ": write failed").c_str()
@@ -734,7 +755,45 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
     if (sufr_hip_is_wide_(ctx0, sd.seq_len))               // windowed build: one GPU, host buffers
         return sufr_hip_create_from_sequence(ctx0, sdp, a, path_out, path_out_len, stats);
     if (a->has_max_query_len || a->seed_mask) n_ctx = 1;   // single-shard builds
+    if (a->has_max_query_len && a->seed_mask) {            // clap's conflicts_with; builder check 163-165 (before the file is touched)
+        sufr_hip_set_error_(ctx0, "Cannot use max_query_len and seed_mask together");
+        return SUFR_HIP_E_CONFLICT;
+    }
     const double t0 = now_s();
+    // The text section (the normalised text, sufr_builder.rs:871) does not wait for the build: its place in the file is
+    // known from the header alone, and the text map 144-160 is a byte table -- host threads map 32 MB pieces and write them
+    // while the GPUs partition and sort (3.1 of the 15.1 GB of a human-sized file, off the D2H + write phase).
+    // (everything is written under "<output>.partial" and renamed at the end: a failed build leaves an existing file alone)
+    const std::string partial = outfile + ".partial";
+    int tfd = ::open(partial.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (tfd < 0) { sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str()); return SUFR_HIP_E_IO; }
+    std::atomic<int> text_failed{0};
+    std::vector<std::thread> text_writers;
+    {
+        const uint64_t text_pos = layout_of(sd, a, 0).text_pos;
+        const uint64_t PIECE = (uint64_t)32 << 20;
+        const uint64_t npieces = (sd.seq_len + PIECE - 1) / PIECE;
+        auto next = std::make_shared<std::atomic<uint64_t>>(0);
+        unsigned W = host_threads(8);
+        if (W > npieces) W = (unsigned)npieces;
+        const int soft = a->ignore_softmask;
+        for (unsigned w = 0; w < W; w++)
+            text_writers.emplace_back([&sd, &text_failed, tfd, text_pos, PIECE, npieces, next, soft]() {
+                std::vector<uint8_t> buf(PIECE);
+                for (uint64_t i; !text_failed && (i = next->fetch_add(1)) < npieces;) {
+                    const uint64_t o = i * PIECE, len = sd.seq_len - o < PIECE ? sd.seq_len - o : PIECE;
+                    (void)sufr_hip_normalize(sd.seq + o, buf.data(), len, soft);
+                    if (!pwrite_all(tfd, buf.data(), len, text_pos + o)) text_failed = 1;
+                }
+            });
+    }
+    auto finish_text = [&]() -> bool {
+        for (auto& x : text_writers) x.join();
+        text_writers.clear();
+        const bool ok = close(tfd) == 0 && !text_failed;
+        tfd = -1;
+        return ok;
+    };
     std::vector<sufr_shard_info> info(n_ctx);
     std::vector<sufr_hip_stats> st(n_ctx);
     std::vector<int> rcs(n_ctx, 0);
@@ -745,33 +804,54 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
         for (auto& x : th) x.join();
     }
     for (int r = 0; r < n_ctx; r++)
-        if (rcs[r]) { if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r])); return rcs[r]; }
+        if (rcs[r]) {
+            (void)finish_text(); (void)unlink(partial.c_str());
+            if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r]));
+            return rcs[r];
+        }
     const double t_built = now_s();
     uint64_t total = 0;
     std::vector<uint64_t> off(n_ctx, 0);
     for (int r = 0; r < n_ctx; r++) { off[r] = total; total += info[r].num_suffixes; }
-    char err[512] = {0};
-    int rc = sufr_write_frame(outfile.c_str(), &sd, a, total, err, sizeof err);
-    if (rc != 0) { sufr_hip_set_error_(ctx0, err); return rc; }
+    int rc = 0;
+    {
+        const SufrLayout L = layout_of(sd, a, total);      // header and name table around the sections (no O_TRUNC: the text is landing)
+        if (!pwrite_all(tfd, L.head.data(), L.head.size(), 0) || !pwrite_all(tfd, L.tail.data(), L.tail.size(), L.tail_pos)) rc = SUFR_HIP_E_IO;
+    }
+    if (rc != 0) {
+        (void)finish_text(); (void)unlink(partial.c_str());
+        sufr_hip_set_error_(ctx0, (outfile + ": write failed").c_str());
+        return rc;
+    }
     {
         std::vector<std::thread> th;
         int prev = -1;                                   // last non-empty shard before r
         for (int r = 0; r < n_ctx; r++) {
             const int pv = prev;
             th.emplace_back([&, r, pv]() {
-                rcs[r] = sufr_hip_shard_write(ctxs[r], &sd, a, outfile.c_str(), info[r].num_suffixes, total, off[r],
-                                              pv >= 0, pv >= 0 ? info[pv].last_suffix : 0, r == 0);
+                rcs[r] = sufr_hip_shard_write(ctxs[r], &sd, a, partial.c_str(), info[r].num_suffixes, total, off[r],
+                                              pv >= 0, pv >= 0 ? info[pv].last_suffix : 0, 0);
             });
             if (info[r].num_suffixes) prev = r;
         }
         for (auto& x : th) x.join();
     }
+    if (!finish_text()) {
+        (void)unlink(partial.c_str());
+        sufr_hip_set_error_(ctx0, (outfile + ": write failed").c_str());
+        return SUFR_HIP_E_IO;
+    }
     for (int r = 0; r < n_ctx; r++)
         if (rcs[r]) {
-            (void)unlink(outfile.c_str());               // no valid header over missing sections left behind
+            (void)unlink(partial.c_str());               // no valid header over missing sections left behind
             if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r]));
             return rcs[r];
         }
+    if (rename(partial.c_str(), outfile.c_str()) != 0) {
+        sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str());
+        (void)unlink(partial.c_str());
+        return SUFR_HIP_E_IO;
+    }
     if (stats) {
         for (int r = 0; r < n_ctx; r++) {
             stats[r] = st[r];
