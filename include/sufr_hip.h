@@ -70,8 +70,9 @@ typedef struct sufr_hip_stats {
     uint32_t partition_workgroups; /* grid of the radix-partition kernel */
     uint32_t partition_variant; /* 3 = k_msd_part_text (bit-packed stream, alphabets of <= 15 symbols), 0 = k_scatter_text (text staging) */
     float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
-    float ms_normalize;         /* k_normalize_pack_dna / k_normalize_bytehist */
-    float ms_hist_text;         /* level-1 histogram over the text (k_msd_hist_text / k_hist_text) + cursor setup */
+    float ms_normalize;         /* k_text_pass_dna (DNA: normalise + pack + run ends + suffix-start bitmap + first-digit histogram, one pass) / k_normalize_bytehist */
+    float ms_hist_text;         /* digit map + cursor setup of level 1 (the first-digit histogram itself is part of k_text_pass_dna; other
+                                   alphabets: k_msd_hist_text / k_hist_text) */
     float ms_partition;         /* k_msd_part_text / k_scatter_text: THE radix-partition kernel (one launch) */
     float ms_passes;            /* further MSD levels + leaf sorts */
     float ms_finish;            /* k_finish of the top level */
@@ -118,13 +119,16 @@ int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_s
  * d_sa / d_lcp are device arrays with room for `cap` entries.  With num_shards > 1 the call builds
  * only the shard_index-th prefix-bucket range (shards are balanced on the device from the k-mer
  * histogram; concatenating shards 0..num_shards-1 gives the full arrays, and the first LCP entry of
- * every shard but the first must be stitched with sufr_hip_lcp_pair).
+ * every shard but the first must be stitched: sufr_hip_stitch_device_u32 does it on the device under the order of the
+ * build -- plain, seed mask or length cap --; sufr_hip_lcp_pair is the host form for plain builds).
  * max_query_len (0 = none) and seed_mask (NULL = none) are the reference's -m / -s builds
  * (sufr_builder.rs:272-300, 310-314, 350-359, 668-683): the seed-mask order (care characters, ties in
  * descending position, LCP in care characters) is reproduced exactly; for max_query_len, where the
  * reference's arrays depend on pivots and merge order, the canonical form is returned (order of the first
- * L characters, ties in descending position, LCP = min(exact, L)).  Both are
- * single-shard builds: with num_shards > 1 they return SUFR_HIP_E_UNSUPPORTED.
+ * L characters, ties in descending position, LCP = min(exact, L)).  Both shard like plain
+ * builds do ("a bounded key, then descending position": equal keys never straddle a first-digit boundary): a seed-mask
+ * build on the first digit of its care-symbol key, a max_query_len build on the first digit of the plain order -- a cap
+ * below 8 symbols (shorter than a digit can be) with num_shards > 1 returns SUFR_HIP_E_UNSUPPORTED.
  * num_partitions and random_seed are accepted for signature parity: the result does not depend on
  * them (pivots are replaced by on-device histogram splitters). */
 int sufr_hip_sort_device_u32(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,
@@ -227,8 +231,8 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx *ctx, const sufr_sequence_data *s
  *
  * One process driving N devices: sufr_hip_create_from_sequence_multi / sufr_hip_create_file_multi build shard r
  * of n_ctx on ctxs[r] (a host thread per context; contexts may share a device) and write ONE .sufr file, byte for
- * byte the file of the single-GPU build.  --max-query-len / --seed-mask builds and texts that need u64 indices are
- * built on ctxs[0] alone (their tie order crosses first-digit buckets).  stats: n_ctx entries or NULL.
+ * byte the file of the single-GPU build, --seed-mask and --max-query-len builds included (round 4; a cap below 8
+ * symbols and texts that need u64 indices are built on ctxs[0] alone).  stats: n_ctx entries or NULL.
  *
  * One process per GPU (torch.distributed / MPI ranks): every rank calls sufr_hip_shard_build, the ranks exchange
  * their sufr_shard_info (24 bytes each: the only collective of the path), rank 0 calls sufr_write_frame, and after

@@ -754,7 +754,7 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
     if (path_out && path_out_len) snprintf(path_out, path_out_len, "%s", outfile.c_str());
     if (sufr_hip_is_wide_(ctx0, sd.seq_len))               // windowed build: one GPU, host buffers
         return sufr_hip_create_from_sequence(ctx0, sdp, a, path_out, path_out_len, stats);
-    if (a->has_max_query_len || a->seed_mask) n_ctx = 1;   // single-shard builds
+    if (a->has_max_query_len && a->max_query_len < 8) n_ctx = 1;   // (a cap shorter than a first digit ties suffixes across shards)
     if (a->has_max_query_len && a->seed_mask) {            // clap's conflicts_with; builder check 163-165 (before the file is touched)
         sufr_hip_set_error_(ctx0, "Cannot use max_query_len and seed_mask together");
         return SUFR_HIP_E_CONFLICT;

@@ -2243,9 +2243,53 @@ k_scatter_slots(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ s
 // so it does not go through the text-streaming partition kernel: eligible positions are listed in
 // descending order and LSD-sorted on the care characters, last block of characters first.
 // ---------------------------------------------------------------------------------------------
+// A shard of a seed-mask build (several GPUs): the suffixes whose first key digit -- the codes of the first `mch` care
+// symbols, b bits each, first one highest; the top digit of the LSD passes of sort_masked -- lies in [lo, hi).  The
+// masked order is "care symbols, then descending position": equal keys never straddle a digit boundary, so the shards
+// concatenate to the one-GPU arrays exactly as the first-digit shards of a plain build do.  hi == 0: no filter.
+struct MaskShard {
+    const uint32_t* offs;       // care offsets (device)
+    int mch, b;
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ uint32_t mask_top_digit(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* lut, uint64_t p,
+                                                   const MaskShard& ms)
+{
+    uint32_t d = 0;
+    for (int c = 0; c < ms.mch; c++) {
+        const uint64_t q = p + ms.offs[c];
+        d = (d << ms.b) | (q < n ? (uint32_t)(lut[text[q]] & 0x3ffu) : 0u);
+    }
+    return d;
+}
+__device__ __forceinline__ bool mask_in_shard(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* lut, uint64_t p,
+                                              const MaskShard& ms)
+{
+    if (ms.hi == 0u) return true;
+    const uint32_t d = mask_top_digit(text, n, lut, p, ms);
+    return d >= ms.lo && d < ms.hi;
+}
+
+// first key digit of every eligible suffix, counted (the "pivots" of a sharded seed-mask build: exact counts, every rank the same)
+__global__ void __launch_bounds__(256)
+k_mask_top_hist(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut, MaskShard ms,
+                uint32_t* __restrict__ hist /* 1 << (mch * b) */)
+{
+    __shared__ uint16_t s_lut[256];
+    __shared__ uint32_t s_h[1024];
+    s_lut[threadIdx.x] = glut[threadIdx.x];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
+    for (int e = 0; e < 16; e++)
+        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u)) atomicAdd(&s_h[mask_top_digit(text, n, s_lut, p0 + e, ms) & 1023u], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
 __global__ void __launch_bounds__(256)
 k_elig_count(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
-             uint32_t* __restrict__ tilecnt)
+             uint32_t* __restrict__ tilecnt, MaskShard ms)
 {
     __shared__ uint16_t s_lut[256];
     __shared__ uint32_t s_w[4];
@@ -2255,7 +2299,7 @@ k_elig_count(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __res
     uint32_t cnt = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u)) cnt++;
+        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u) && mask_in_shard(text, n, s_lut, p0 + e, ms)) cnt++;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, WAVE);
     if (lane_id() == 0) s_w[threadIdx.x >> 6] = cnt;
@@ -2265,7 +2309,7 @@ k_elig_count(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __res
 
 __global__ void __launch_bounds__(256)
 k_elig_emit_desc(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ glut,
-                 const uint32_t* __restrict__ tileoff, uint32_t s, uint32_t* __restrict__ idx)
+                 const uint32_t* __restrict__ tileoff, uint32_t s, uint32_t* __restrict__ idx, MaskShard ms)
 {
     __shared__ uint16_t s_lut[256];
     __shared__ uint32_t s_w[4];
@@ -2275,7 +2319,7 @@ k_elig_emit_desc(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
     uint32_t el = 0, cnt = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u)) { el |= 1u << e; cnt++; }
+        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u) && mask_in_shard(text, n, s_lut, p0 + e, ms)) { el |= 1u << e; cnt++; }
     uint32_t incl = cnt;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -2402,10 +2446,31 @@ k_mask_lcp_staged(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* 
 // Exact LCP of two suffixes of the device text: find_lcp(a, b, text_len, 0) of write()'s boundary fix
 // (sufr_builder.rs:893-902), for the first record of a shard against the last record of the shard before it.
 // One workgroup, 4096 characters per round.
+// Under the order of the build (StitchOrder): a seed mask counts equal care symbols while both sides are inside the text
+// (the mask arm of find_lcp, 272-300), --max-query-len caps the count (310-314).
+struct StitchOrder {
+    const uint32_t* offs;       // care offsets of the seed mask (device), or nullptr
+    uint32_t weight;
+    uint64_t cap;               // max_query_len, 0: none
+};
+__device__ __forceinline__ uint64_t masked_pair_lcp(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b,
+                                                    const StitchOrder& so)
+{
+    uint32_t c = 0;
+    while (c < so.weight) {
+        const uint64_t qa = a + so.offs[c], qb = b + so.offs[c];
+        if (qa >= n || qb >= n || text[qa] != text[qb]) break;
+        c++;
+    }
+    return c;
+}
+
 __global__ void __launch_bounds__(256)
-k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b, unsigned long long* __restrict__ out)
+k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b, unsigned long long* __restrict__ out,
+           StitchOrder so)
 {
     __shared__ uint32_t s_first;
+    if (so.offs) { if (threadIdx.x == 0) *out = masked_pair_lcp(text, n, a, b, so); return; }
     const uint64_t lim = n - (a > b ? a : b);          // characters both suffixes have
     for (uint64_t k = 0;; k += 4096) {
         if (threadIdx.x == 0) s_first = 0xffffffffu;
@@ -2420,7 +2485,10 @@ k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b,
         __syncthreads();
         const uint32_t f = s_first;
         __syncthreads();
-        if (f != 0xffffffffu) { if (threadIdx.x == 0) *out = k + f; return; }
+        if (f != 0xffffffffu || (so.cap && k + 4096 >= so.cap)) {
+            if (threadIdx.x == 0) { uint64_t v = f != 0xffffffffu ? k + f : so.cap; if (so.cap && v > so.cap) v = so.cap; *out = v; }
+            return;
+        }
     }
 }
 
@@ -2430,7 +2498,7 @@ k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b,
 // No host round trip: the pair is read from `bounds` here.
 __global__ void __launch_bounds__(256)
 k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long long* __restrict__ bounds, uint32_t rank,
-             uint32_t* __restrict__ lcp)
+             uint32_t* __restrict__ lcp, StitchOrder so)
 {
     __shared__ uint32_t s_first;
     if (bounds[(size_t)rank * 3 + 2] == 0ull) return;
@@ -2438,6 +2506,7 @@ k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long l
     while (prev >= 0 && bounds[(size_t)prev * 3 + 2] == 0ull) prev--;
     if (prev < 0) return;                                  // the globally first suffix: LCP 0, as the build left it
     const uint64_t a = bounds[(size_t)prev * 3 + 1], b = bounds[(size_t)rank * 3];
+    if (so.offs) { if (threadIdx.x == 0) lcp[0] = (uint32_t)masked_pair_lcp(text, n, a, b, so); return; }
     const uint64_t lim = n - (a > b ? a : b);          // characters both suffixes have
     for (uint64_t k = 0;; k += 4096) {
         if (threadIdx.x == 0) s_first = 0xffffffffu;
@@ -2452,7 +2521,10 @@ k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long l
         __syncthreads();
         const uint32_t f = s_first;
         __syncthreads();
-        if (f != 0xffffffffu) { if (threadIdx.x == 0) lcp[0] = (uint32_t)(k + f); return; }
+        if (f != 0xffffffffu || (so.cap && k + 4096 >= so.cap)) {
+            if (threadIdx.x == 0) { uint64_t v = f != 0xffffffffu ? k + f : so.cap; if (so.cap && v > so.cap) v = so.cap; lcp[0] = (uint32_t)v; }
+            return;
+        }
     }
 }
 

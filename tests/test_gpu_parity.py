@@ -96,7 +96,8 @@ def test_native_cli_binary_golden(tmp_path):
 def test_multi_device_create_is_byte_identical(tmp_path, name):
     """`sufr --devices 0,0,0 create` (three shards, here on one GPU): every shard writes its own range of the one
     file, the boundary LCPs are stitched on the device -- the bytes are those of the golden / single-GPU file.
-    (--seed-mask builds are single-shard by design: the call degrades to one context.)"""
+    (--seed-mask builds shard on their own first key digit and stitch with the care-symbol LCP: uniprot-masked.sufr too
+    comes out of three contexts.)"""
     case = dict(GOLDEN_CASES[name])
     fa = GOLDEN / "inputs" / case.pop("fa")
     delim = case.pop("delimiter", b"%").decode()
@@ -697,6 +698,53 @@ def test_fuzz_shards_concatenate_to_the_single_build(block):
     db.close()
 
 
+def _sharded_arrays(db, d_text, n, shards, **kw):
+    """every shard built on the one context, its first LCP stitched on the device under the order of the build
+    (sufr_hip_stitch_device_u32), concatenated"""
+    from sufr_amd import shards as sh
+    parts_sa, parts_lcp, bounds = [], [], torch.zeros(shards, 3, dtype=torch.int64, device="cuda")
+    for r in range(shards):
+        psa, plcp = db.sort(d_text, shard_index=r, num_shards=shards, **kw)
+        cnt = psa.numel()
+        if cnt:
+            bounds[r, 0] = int(psa[0]) & 0xFFFFFFFF; bounds[r, 1] = int(psa[-1]) & 0xFFFFFFFF; bounds[r, 2] = cnt
+            plcp = plcp.clone()
+            sh.stitch_device(db.ctx, n, bounds[:r + 1].contiguous(), r, plcp)
+            db.ctx.synchronize()
+        parts_sa.append(psa.cpu().numpy().view(np.uint32).copy()); parts_lcp.append(plcp.cpu().numpy().view(np.uint32).copy())
+    return np.concatenate(parts_sa), np.concatenate(parts_lcp), [p.size for p in parts_sa]
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_shards_of_masked_and_capped_builds_concatenate_to_the_single_build(block):
+    """--seed-mask and --max-query-len builds over 2 / 3 / 5 / 8 shards (missing 2): a masked build is split on its
+    own first key digit, a capped one on the first digit of the plain order; the boundary LCP is the care-symbol count /
+    the capped count (k_lcp_stitch under the order of the build).  Concatenated, the shards are the one-GPU arrays."""
+    rng = np.random.default_rng(8100 + block)
+    db = sufr_amd.DeviceBuilder(0)
+    for case in range(16):
+        raw = _fuzz_text(rng)
+        is_dna = bool(rng.random() < 0.6)
+        soft = bool(rng.random() < 0.5)
+        kw = dict(is_dna=is_dna, ignore_softmask=soft, raw_text=True)
+        if rng.random() < 0.6:
+            ones = int(rng.integers(1, 5))                   # regex ^1+0[01]*1$ (types.rs:163-166)
+            kw["seed_mask"] = "1" * ones + "0" + "".join(rng.choice(["0", "1"], size=int(rng.integers(0, 16)))) + "1"
+        else:
+            kw["max_query_len"] = int(rng.choice([8, 9, 12, 16, 31, 100]))
+        d_text = torch.from_numpy(raw).cuda()
+        fsa, flcp = db.sort(d_text, **kw)
+        fsa = fsa.cpu().numpy().view(np.uint32).copy(); flcp = flcp.cpu().numpy().view(np.uint32).copy()
+        shards = int(rng.choice([2, 3, 5, 8]))
+        csa, clcp, sizes = _sharded_arrays(db, d_text, raw.size, shards, **kw)
+        ctxt = f"block {block} case {case} n={raw.size} shards={shards} sizes={sizes} {kw}"
+        assert np.array_equal(csa, fsa), ctxt
+        assert np.array_equal(clcp, flcp), ctxt
+    with pytest.raises(sufr_amd.SufrHipError):              # a cap shorter than a first digit ties suffixes across shards
+        db.sort(d_text, is_dna=True, max_query_len=3, shard_index=0, num_shards=2)
+    db.close()
+
+
 @pytest.mark.parametrize("kind", range(8))
 def test_fuzz_structured_texts_against_oracle(ctx, oracle, kind):
     """20 k - 400 k texts with the structures that stress different parts of the pipeline: families of
@@ -801,6 +849,12 @@ def test_seed_mask_build_at_100mb_equals_oracle(oracle):
     osa, olcp, _ = oracle.build(norm, is_dna=True, num_partitions=64, seed_mask=mask, threads=os.cpu_count() or 1)
     assert np.array_equal(sa.cpu().numpy().view(np.uint32), osa)
     assert np.array_equal(lcp.cpu().numpy().view(np.uint32), olcp)
+    # ... and as eight shards (what eight GPUs build): split on the first key digit of the masked order, first LCPs stitched
+    # with the care-symbol count, concatenated
+    del sa, lcp
+    csa, clcp, sizes = _sharded_arrays(db, x, x.numel(), 8, is_dna=True, raw_text=True, num_partitions=64, seed_mask=mask)
+    assert min(sizes) > 0 and max(sizes) < 2 * (sum(sizes) // 8)
+    assert np.array_equal(csa, osa) and np.array_equal(clcp, olcp)
     db.close()
 
 
