@@ -59,7 +59,7 @@ def pmc_traffic_bytes(workload: str):
     import glob
     files = sorted(glob.glob(str(ROOT / "profiles" / f"r*_pmc_{workload}.csv")))
     if not files:
-        return None
+        return None, None
     fetch = write = None
     for r in csv.DictReader(open(files[-1])):
         if "k_msd_part_text" in r["kernel"] or "k_scatter_text" in r["kernel"]:
@@ -68,8 +68,8 @@ def pmc_traffic_bytes(workload: str):
             if r["counter"] == "WRITE_SIZE":
                 write = float(r["largest_dispatch_value"])
     if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, "profiles/" + Path(files[-1]).name
 
 
 def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: float = 15.0):
@@ -407,7 +407,8 @@ def main():
     search = None
     if world == 1 and not args.no_verify:
         # outside the timed region: the arrays of the last timed step against the text (sufr_amd/verify.py)
-        from sufr_amd import verify
+        sys.path.insert(0, str(ROOT / "tests"))
+        import gpu_verify as verify          # the GPU-side property checker: test infrastructure, like oracle/
         verify.check_permutation(text, sa, is_dna=flags.get("is_dna", False), allow_ambiguity=False,
                                  ignore_softmask=soft)
         lut = verify.normalize_lut(dev, soft)
@@ -434,6 +435,9 @@ def main():
         # SURVEY.md 8(d) / BASELINE.md section 4; s = suffixes this rank keeps
         alg_bytes = n + 4 * st["num_suffixes"]
         achieved = alg_bytes / (avg["ms_partition"] * 1e-3) / 1e9 if avg["ms_partition"] > 0 else 0.0
+        # HBM bytes of that launch from the PMC counters: read from the committed summary of a profiled run of this same
+        # command (the counters need rocprofv3 passes of their own), and labelled with the file they come from
+        traffic, traffic_src = pmc_traffic_bytes(args.workload) if world == 1 and not args.bases else (None, None)
         out = {
             "metric": "suffixes sorted/sec (SA+LCP)",
             "value": s_total * args.steps / dt,
@@ -455,7 +459,7 @@ def main():
                          + " (radix partition: text -> (key, index) records in first-digit buckets)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(args.workload) if world == 1 and not args.bases else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": alg_bytes, "ms": avg["ms_partition"]},
             "device_ms": avg,
             "verified": verified,

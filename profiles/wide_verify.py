@@ -5,7 +5,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sufr_amd
-from sufr_amd import verify
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import gpu_verify as verify
 
 n = int(float(sys.argv[1])); window = int(float(sys.argv[2])); margin = int(float(sys.argv[3]))
 dev = "cuda"

@@ -944,7 +944,7 @@ def test_human_config_c4_properties():
     weighted checksum and an xor of hashes against the eligibility mask); 10^6 sampled adjacent ranks plus 10^5
     sampled from the ranks with LCP >= 64 (the ones the levels beyond the packed key produce) are in order with
     the EXACT LCP, however long (walked through megabase N runs); 8 shards concatenate to the same arrays."""
-    from sufr_amd import verify
+    import gpu_verify as verify
     x, _ = synth.syn_human(3_100_000_000, seed=4, device="cuda")
     db = sufr_amd.DeviceBuilder(0)
     out_sa = torch.empty(1_530_000_000, dtype=torch.int32, device="cuda")

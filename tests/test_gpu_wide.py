@@ -10,7 +10,8 @@ import pytest
 import torch
 
 import sufr_amd
-from sufr_amd import synth, verify
+from sufr_amd import synth
+import gpu_verify as verify
 from oracle_helper import GOLDEN, GOLDEN_CASES
 
 pytestmark = pytest.mark.gpu
