@@ -938,6 +938,30 @@ def test_human_prefix_400mb_deep_modes_section_hashes_equal_oracle(oracle, mode)
     db.close()
 
 
+def test_human_config_c4_whole_arrays_hash_equal_to_the_oracle(oracle):
+    """BASELINE config C4 at FULL size (3.1 Gb stand-in, --dna --ignore-softmask -n 256; 1.5 G suffixes): xxh64 of the whole SA
+    and of the whole LCP array equal the hashes of the oracle's arrays (whole-array evidence used to stop
+    at the 400 Mb prefix).  The oracle takes ~50 s on 32 host threads and ~70 GB of host memory: skipped on smaller hosts."""
+    import xxhash
+    mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
+    if mem_gb < 200 or (os.cpu_count() or 1) < 16:
+        pytest.skip(f"the oracle at 3.1 Gb needs ~70 GB of host memory and a minute of 32 threads (host: {mem_gb:.0f} GB, {os.cpu_count()} cores)")
+    x, _ = synth.syn_human(3_100_000_000, seed=4, device="cuda")
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, is_dna=True, ignore_softmask=True, raw_text=True, num_partitions=256)
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    raw = x.cpu().numpy()
+    del x, sa, lcp
+    db.close()
+    torch.cuda.empty_cache()
+    norm = oracle.normalize(raw, True)
+    del raw
+    osa, olcp, _ = oracle.build(norm, is_dna=True, num_partitions=256, threads=min(32, os.cpu_count() or 1))
+    assert gsa.size == osa.size == 1_500_223_556
+    assert xxhash.xxh64(gsa.tobytes()).hexdigest() == xxhash.xxh64(osa.tobytes()).hexdigest()
+    assert xxhash.xxh64(glcp.tobytes()).hexdigest() == xxhash.xxh64(olcp.tobytes()).hexdigest()
+
+
 def test_human_config_c4_properties():
     """BASELINE config C4 size (3.1 Gb stand-in, --dna --ignore-softmask): size-independent properties checked
     on the GPU itself (sufr_amd/verify.py) -- SA is a permutation of the eligible positions (count, sum, a
