@@ -68,7 +68,8 @@ typedef struct sufr_hip_stats {
     uint64_t deep_records;      /* records processed by deeper levels (all levels) */
     uint32_t top_lo, top_hi;    /* prefix-bucket range of this shard [lo, hi) */
     uint32_t partition_workgroups; /* grid of the radix-partition kernel */
-    uint32_t partition_variant; /* 3 = k_msd_part_text (bit-packed stream, alphabets of <= 15 symbols), 0 = k_scatter_text (text staging) */
+    uint32_t partition_variant; /* 3 = k_msd_part_text (bit-packed stream, alphabets of <= 15 symbols), 4 = the same with half-size tiles
+                                   (more than ~3 200 first digits), 0 = k_scatter_text (text staging) */
     float ms_total;             /* text resident in HBM -> SA+LCP resident in HBM */
     float ms_normalize;         /* k_text_pass_dna (DNA: normalise + pack + run ends + suffix-start bitmap + first-digit histogram, one pass) / k_normalize_bytehist */
     float ms_hist_text;         /* digit map + cursor setup of level 1 (the first-digit histogram itself is part of k_text_pass_dna; other

@@ -938,6 +938,43 @@ def test_human_prefix_400mb_deep_modes_section_hashes_equal_oracle(oracle, mode)
     db.close()
 
 
+@pytest.mark.parametrize("kind", ["b2", "b4", "b3_many_digits", "b3_many_digits_sharded"])
+def test_partition_kernel_geometries_at_40mb_equal_oracle(oracle, kind):
+    """The instantiations of k_msd_part_text that the genome-shaped tests do not reach, at a size that takes the 1024-thread
+    tiles (n >= 2^25): 2-bit codes (three symbols), 4-bit codes (twelve symbols), and 3-bit codes whose first digits are too
+    many for a 65 536-position tile beside the counter arrays -- A C G T N mixing freely under --allow-ambiguity plus a few
+    stray delimiters: ~3 500 five-mers, the half-size-tile fallback (RNDS = 1) --, the last one also as five shards.
+    Whole SA and LCP against the oracle."""
+    rng = np.random.default_rng({"b2": 1, "b4": 2}.get(kind, 3))
+    n = 40_000_000
+    if kind == "b2":
+        raw = np.frombuffer(b"ACG", dtype=np.uint8)[rng.integers(0, 3, n)]
+        kw = dict(is_dna=False)
+    elif kind == "b4":
+        raw = np.frombuffer(b"ACDEFGHIKLMN", dtype=np.uint8)[rng.integers(0, 12, n)]
+        kw = dict(is_dna=False)
+    else:
+        # A C G T N mixing freely (5^5 = 3 125 five-mers) + 80 stray '%' (five new five-mers each): ~3 500 first digits
+        raw = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, n)].copy()
+        raw[rng.integers(0, n - 1, 80)] = ord("%")
+        kw = dict(is_dna=True, allow_ambiguity=True)
+    raw = raw.copy()
+    raw[-1] = ord("$")
+    x = torch.from_numpy(raw).cuda()
+    db = sufr_amd.DeviceBuilder(0)
+    if kind.endswith("sharded"):
+        gsa, glcp, sizes = _sharded_arrays(db, x, n, 5, raw_text=True, **kw)
+        assert min(sizes) > 0
+    else:
+        sa, lcp = db.sort(x, raw_text=True, **kw)
+        gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+        assert db.stats.partition_variant == (4 if kind.startswith("b3") else 3)     # the packed-stream kernel; half-size tiles for b3
+    osa, olcp, _ = oracle.build(raw, threads=min(32, os.cpu_count() or 1), **kw)
+    assert np.array_equal(gsa, osa)
+    assert np.array_equal(glcp, olcp)
+    db.close()
+
+
 def test_human_config_c4_whole_arrays_hash_equal_to_the_oracle(oracle):
     """BASELINE config C4 at FULL size (3.1 Gb stand-in, --dna --ignore-softmask -n 256; 1.5 G suffixes): xxh64 of the whole SA
     and of the whole LCP array equal the hashes of the oracle's arrays (whole-array evidence used to stop

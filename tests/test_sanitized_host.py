@@ -4,8 +4,8 @@ bzip2 / xz through hand-declared stream structs; the mmap'd .sufr writer) and su
 files, host search) with g++ -fsanitize=address,undefined; the device side of the ABI is stubbed (sufr_host_stubs.cpp).
 The library is loaded in child processes with libasan preloaded:
 
-* the reader / writer tests of tests/test_host_logic.py run against it (the query tests too in profiles/asan_host.sh,
-  whose log is profiles/r04_asan_host.txt -- three minutes under the sanitizer, too long for this suite);
+* the reader / writer tests of tests/test_host_logic.py and the query tests of tests/test_query.py run against it
+  (profiles/asan_host.sh is the long form with more fuzz seeds; its log is profiles/r04_asan_host.txt);
 * tests/fuzz_host.py feeds it damaged FASTA / FASTQ / gz / bz2 / xz / .sufr inputs: every one ends in data or in an error
   string, none in a crash or a sanitizer report.
 """
@@ -52,10 +52,13 @@ def test_sanitizer_build_exports_the_whole_abi():
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_reader_and_writer_tests_pass_under_the_sanitizers():
+def test_reader_writer_and_query_tests_pass_under_the_sanitizers():
     env = _asan_env()
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_logic.py", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
-                        "--deselect", "tests/test_host_logic.py::test_build_fails_loudly_without_gpu"],
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_logic.py", "tests/test_query.py", "-q", "-m", "not gpu",
+                        "-p", "no:cacheprovider",
+                        "--deselect", "tests/test_host_logic.py::test_build_fails_loudly_without_gpu",
+                        # (compiles the kernels to ISA with hipcc: nothing of the host code, minutes under a preloaded libasan)
+                        "--deselect", "tests/test_host_logic.py::test_no_flat_instructions_in_the_kernels"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     _clean(r.stdout + r.stderr)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
@@ -63,7 +66,7 @@ def test_reader_and_writer_tests_pass_under_the_sanitizers():
 
 def test_damaged_inputs_end_in_an_error_string_never_in_a_crash():
     env = _asan_env()
-    r = subprocess.run([sys.executable, "tests/fuzz_host.py", "300", "3"], cwd=ROOT, env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, "tests/fuzz_host.py", "1500", "3"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=1200)
     _clean(r.stdout + r.stderr)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
