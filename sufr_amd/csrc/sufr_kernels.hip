@@ -1924,14 +1924,16 @@ k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, RunTable R,
               const uint16_t* __restrict__ glut, const uint32_t* __restrict__ idx,
               const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth,
               const uint8_t* __restrict__ segperiod, uint32_t m, KeyParams kp, uint64_t* __restrict__ keys,
-              uint32_t* __restrict__ max_token_bits)
+              uint32_t* __restrict__ max_token_bits, int only_periodic = 0)
 {
     __shared__ uint16_t s_lut[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
     uint32_t tb = 0;
-    if (e < m) {
+    // only_periodic: keys[] already holds the plain-run keys of this depth (carried over by k_build_level); only the members of
+    // groups that were found periodic since take a new one
+    if (e < m && !(only_periodic && segperiod[seg[e]] == 1)) {
         const uint64_t k =
             make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]], kp.packed);
         keys[e] = k;
@@ -1988,6 +1990,7 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
         }
     }
     newperiod[k] = (uint8_t)pi;
+    if (pi != 1) atomicAdd(maxsize + 1, 1u);     // periodic groups of the level (rare): the high half of the 8-byte scalar
     // (only a group that would raise the value: atomics on one address are served one by one in the L2)
     if (sz > __hip_atomic_load(maxsize, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxsize, sz);
 }
@@ -1998,7 +2001,8 @@ __global__ void __launch_bounds__(256)
 k_build_level(const uint32_t* __restrict__ idx, uint32_t istride, const uint32_t* __restrict__ opos,
               const uint32_t* __restrict__ heads, const uint32_t* __restrict__ start, uint32_t L,
               uint32_t m_new, uint32_t* __restrict__ idx_new, uint32_t* __restrict__ seg_new,
-              uint32_t* __restrict__ opos_new)
+              uint32_t* __restrict__ opos_new, const uint64_t* __restrict__ key_old = nullptr,
+              uint64_t* __restrict__ key_new = nullptr)
 {
     // the 256 slots of a workgroup lie in a handful of consecutive groups: two lanes bracket them over the whole table
     // (19 dependent probes at 4 * 10^5 groups), the others search the bracket
@@ -2025,6 +2029,8 @@ k_build_level(const uint32_t* __restrict__ idx, uint32_t istride, const uint32_t
     idx_new[t] = idx[(size_t)src * istride];     // istride 3: the index field of 12-byte records
     seg_new[t] = lo;
     opos_new[t] = DEEP ? opos[src] : src;
+    // (groups that are re-keyed at the depth their keys were taken at -- the tie level's whole runs -- keep their keys)
+    if (key_new) key_new[t] = key_old[src];
 }
 
 // ---------------------------------------------------------------------------------------------

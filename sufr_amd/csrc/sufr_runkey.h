@@ -158,6 +158,31 @@ SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
     return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
 }
 
+// lowest bit of every whole `bits`-bit code of a 64-bit word filled from the top (code j in bits [64 - bits (j + 1), 64 - bits j))
+SUFR_HD uint64_t code_lsb_mask(int bits)
+{
+    switch (bits) {
+        case 1: return ~0ull;
+        case 2: return ~0ull / 3u;
+        case 3: return ~0ull / 7u;
+        case 4: return ~0ull / 15u;
+        case 5: return ~0ull / 31u;
+        case 6: return ~0ull / 63u;
+        case 7: return ~0ull / 127u;
+        case 8: return ~0ull / 255u;
+        default: return ~0ull / 511u;
+    }
+}
+
+// number of leading whole codes of `v` (codes from the top) that equal `code`; 64 / bits when all of them do
+SUFR_HD uint32_t leading_equal_codes(uint64_t v, uint32_t code, int bits)
+{
+    const uint32_t K = div_by_bits(64u, bits);
+    const int spare = 64 - (int)K * bits;                      // low bits that hold no whole code
+    const uint64_t x = (v ^ ((uint64_t)code * code_lsb_mask(bits))) >> spare;
+    return x ? div_by_bits((uint32_t)__builtin_clzll(x << spare), bits) : K;
+}
+
 // pi = period assumed for the group (1 = plain runs, served by the run-end table).  Any pi <= the length of
 // the group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
 // periodic extension up to the shorter of their two break points, and at the break the suffix whose text
@@ -190,7 +215,10 @@ SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
         codes_at(q - 1, vprev, vq);
         uint32_t cprev = (uint32_t)(vprev >> (64 - bits)), cq = (uint32_t)(vq >> (64 - bits));
         if (q < n && cq == cprev) {
-            rem = run_len_at(q, rt);
+            // a run that ends inside the ~20 codes in hand (every fourth suffix of a DNA text continues its last character;
+            // almost all such runs are a few characters long) needs no look at the run-end table: another random sector
+            const uint32_t eq = leading_equal_codes(vq, cprev, bits);
+            rem = eq < div_by_bits(64u, bits) ? eq : run_len_at(q, rt);
             codes_at(q + rem - 1, vprev, vq);
             cprev = (uint32_t)(vprev >> (64 - bits)); cq = (uint32_t)(vq >> (64 - bits));
         }
