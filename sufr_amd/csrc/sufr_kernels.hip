@@ -1479,6 +1479,53 @@ __device__ __forceinline__ uint64_t walk_lcp(const uint8_t* __restrict__ text, u
     return k;
 }
 
+// The same walk on the bit-packed code stream (alphabets of <= 4 bits per symbol): 42 symbols of a 3-bit alphabet per step, 24
+// bytes -- one sector per suffix, usually the one its run key was just read from -- where the byte text costs two to four.
+// Codes are the ranks of the bytes and 0 past the end of the text: equal codes <=> equal bytes, code order = byte order.
+// `ca`, `cb`: the codes at the mismatch (valid when the result is below the limit).
+__device__ __forceinline__ uint64_t walk_lcp_packed(const uint8_t* __restrict__ packed, int bits, uint64_t n, uint64_t a, uint64_t b,
+                                                    uint64_t cap, uint32_t& ca, uint32_t& cb)
+{
+    uint64_t lim = n - (a > b ? a : b);
+    if (lim > cap) lim = cap;
+    const uint32_t K = div_by_bits(64u, bits);                 // whole codes per 64-bit word
+    const int spare = 64 - (int)K * bits;
+    uint64_t k = 0;
+    ca = cb = 0;
+    while (k < lim) {
+        const uint64_t oa = (a + k) * (uint64_t)bits, ob = (b + k) * (uint64_t)bits;
+        const uint8_t* pa = packed + (oa >> 3);
+        const uint8_t* pb = packed + (ob >> 3);
+        uint64_t wa[3], wb[3];                                  // 24 bytes each: two words of K codes behind a bit offset below 8
+#pragma unroll
+        for (int u = 0; u < 3; u++) { wa[u] = __builtin_bswap64(load_u64_unaligned(pa + 8 * u)); wb[u] = __builtin_bswap64(load_u64_unaligned(pb + 8 * u)); }
+        const uint32_t sa = (uint32_t)(oa & 7u), sb = (uint32_t)(ob & 7u);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t qa = sa + (uint32_t)j * K * (uint32_t)bits, qb = sb + (uint32_t)j * K * (uint32_t)bits;   // < 8 + 64
+            const uint32_t ra = qa & 63u, rb = qb & 63u;
+            // (selects, not indexed registers)
+            const uint64_t ha = qa < 64u ? wa[0] : wa[1], la = qa < 64u ? wa[1] : wa[2];
+            const uint64_t hb = qb < 64u ? wb[0] : wb[1], lb = qb < 64u ? wb[1] : wb[2];
+            const uint64_t va = ra ? ((ha << ra) | (la >> (64u - ra))) : ha;
+            const uint64_t vb = rb ? ((hb << rb) | (lb >> (64u - rb))) : hb;
+            const uint64_t x = (va ^ vb) >> spare;
+            if (x) {
+                const uint32_t c = div_by_bits((uint32_t)__builtin_clzll(x << spare), bits);
+                k += c;
+                if (k >= lim) return lim;
+                const int sh = 64 - (int)(c + 1u) * bits;
+                ca = (uint32_t)(va >> sh) & ((1u << bits) - 1u);
+                cb = (uint32_t)(vb >> sh) & ((1u << bits) - 1u);
+                return k;
+            }
+            k += K;
+            if (k >= lim) return lim;
+        }
+    }
+    return lim;
+}
+
 // Walk keys: a member of a tie group keyed by its common prefix L with the group's FIRST member (the reference),
 // beyond the depth all members share.  A member that leaves the reference's text earlier than another is smaller than
 // it iff its character there is below the reference's: {below the reference, L ascending} < reference < {above, L
@@ -1507,11 +1554,10 @@ __device__ __forceinline__ uint32_t walk_key_common(uint64_t a, uint64_t b)
 // for the sake of two or three.  Instead the window's tie runs are written back in sorted order and
 // described by four 64-bit lane masks (members / run heads); k_build_ties packs them into a dense level
 // whose finisher then works with all lanes active.
-// CROSS: second pass over the windows that flagged a group running past their end: the wave's window
-// now starts at that group's head, so any group of <= 128 records is finished here and only larger ones
-// stay flagged for the next level (without this pass a straddling small group would be deferred level
-// after level: one in five straddles again after repacking).
-template <bool DEEP, bool TIES_OUT, bool CROSS>
+// PLANNED: the windows come from k_plan_windows: wave i takes the records [wl_head[i], wl_head[i] + wl_flag[i]) (at most 128),
+// a window that starts and ends at group heads -- every group in it is finished here; the groups above a window are already
+// on the next level's list.  (Rounds 2-3: fixed windows of 128, groups crossing their end re-done by a second launch.)
+template <bool DEEP, bool TIES_OUT, bool PLANNED>
 __global__ void __launch_bounds__(256, 5)       // 5 waves per SIMD (96 registers, no spill): the rounds are chains of random reads
 k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
          const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
@@ -1536,13 +1582,12 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
 
-    // one wave per window of 128 consecutive records; a group that crosses the window's end is "large"
-    // CROSS: wave i works on the i-th flagged group (wl_head = compact list of their heads, wl_flag[i] is
-    // set to 1 while the group stays large and to 0 once it has been finished here)
+    // one wave per window: PLANNED -- the i-th planned window; else 128 consecutive records, and a group that crosses the
+    // window's end is "large"
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (CROSS ? (wave >= ncross) : ((uint64_t)wave * 128 >= m)) return;
-    uint64_t base64 = CROSS ? (uint64_t)wl_head[wave] : (uint64_t)wave * 128;
-    if (CROSS && (threadIdx.x & 63u) == 0) wl_flag[wave] = 1u;
+    if (PLANNED ? (wave >= ncross) : ((uint64_t)wave * 128 >= m)) return;
+    uint64_t base64 = PLANNED ? (uint64_t)wl_head[wave] : (uint64_t)wave * 128;
+    const uint32_t wcount = PLANNED ? wl_flag[wave] : 128u;
     const int wv = threadIdx.x >> 6;
     auto sk = SUFR_LDS_VOLATILE(uint64_t, sh_key[wv]);
     auto si = SUFR_LDS_VOLATILE(uint32_t, sh_idx[wv]);
@@ -1555,7 +1600,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     // overhangs by more than that (a level of tie runs of ~12 records: half the windows flagged a crossing group for the
     // second pass when every wave sat on its own 128 records).
     uint32_t own_limit = 128u;                      // groups whose head slot is below this are this wave's
-    if (DEEP && !TIES_OUT && !CROSS) {
+    if (DEEP && !TIES_OUT && !PLANNED) {
         const uint32_t b0 = (uint32_t)base64;
         const uint32_t a0 = b0 + (uint32_t)ln, a1 = b0 + 64u + (uint32_t)ln;
         const bool v0 = a0 < m, v1 = a1 < m;
@@ -1581,7 +1626,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     }
     const uint32_t base = (uint32_t)base64;
     const uint32_t j0 = base + ln, j1 = base + 64 + ln;
-    const bool in0 = j0 < m, in1 = j1 < m;
+    const bool in0 = j0 < m && (uint32_t)ln < wcount, in1 = j1 < m && 64u + (uint32_t)ln < wcount;
 
     uint64_t k0 = in0 ? keys[j0] : ~0ull, k1 = in1 ? keys[j1] : ~0ull;
     uint32_t i0 = in0 ? idxs[j0] : 0u, i1 = in1 ? idxs[j1] : 0u;
@@ -1593,7 +1638,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     // record before the window (slot -1) and after it (slot 128)
     uint64_t kprev = 0, knext = 0; uint32_t sprev = 0, snext = 0;
     const bool has_prev = base > 0;
-    const bool has_next = (base64 + 128) < m;
+    const bool has_next = !PLANNED && (base64 + 128) < m;     // (a planned window ends at a head)
     if (has_prev) { kprev = keys[base - 1]; if (DEEP) sprev = segs[base - 1]; }
     if (has_next) { knext = keys[base + 128]; if (DEEP) snext = segs[base + 128]; }
 
@@ -1623,27 +1668,24 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     const int g0 = mask_prev_set(H0, H1, ln), g1 = mask_prev_set(H0, H1, 64 + ln);
     const int none = h128 ? 128 : 1000;
     const int nx0 = mask_next_set(H0, H1, ln, none), nx1 = mask_next_set(H0, H1, 64 + ln, none);
-    // group starts inside this window (CROSS: only the flagged group, whose head is slot 0)
-    const bool own0 = in0 && (CROSS ? g0 == 0 : (g0 >= 0 && (uint32_t)g0 < own_limit));
-    const bool own1 = in1 && (CROSS ? g1 == 0 : (g1 >= 0 && (uint32_t)g1 < own_limit));
+    // group starts inside this window (PLANNED: all of them do)
+    const bool own0 = in0 && (PLANNED || (g0 >= 0 && (uint32_t)g0 < own_limit));
+    const bool own1 = in1 && (PLANNED || (g1 >= 0 && (uint32_t)g1 < own_limit));
     const bool small0 = own0 && nx0 <= 128, small1 = own1 && nx1 <= 128;
     // Only the window's last group can run past its end, so a window reports at most one large group:
     // a flag and a head position per window, compacted afterwards by a scan (k_compact_large).  (Appending
     // with one global atomic counter serialises: a quarter of all windows end in a crossing group.)
     const bool lg0 = own0 && h0 && !small0, lg1 = own1 && h1 && !small1;
-    if (CROSS) {
-        if (__ballot(lg0) != 0ull) return;       // larger than a window: stays flagged for the next level
-    } else
-    if (lg0) {
+    if (!PLANNED && lg0) {
         wl_head[wave] = j0;
         if (!first0) LCP[DEEP ? opos[j0] : j0] = lcp0;
         else if (!DEEP) LCP[j0] = 0;
     }
-    if (lg1) {
+    if (!PLANNED && lg1) {
         wl_head[wave] = j1;
         if (!first1) LCP[DEEP ? opos[j1] : j1] = lcp1;
     }
-    if (!CROSS) {
+    if (!PLANNED) {
         const uint64_t any_large = __ballot(lg0 || lg1);
         if (ln == 0) wl_flag[wave] = any_large ? 1u : 0u;
     }
@@ -1729,13 +1771,15 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
                     const uint32_t other = si[slot + 1];
                     const uint64_t a = (uint64_t)mine + dnew, b = (uint64_t)other + dnew;
                     const uint64_t lim = n - (a > b ? a : b);        // characters both suffixes have
-                    const uint64_t k = walk_lcp(text, n, a, b, WALK_CAP);
+                    uint32_t ca = 0, cb = 0;
+                    const uint64_t k = kp.packed ? walk_lcp_packed(kp.packed, kp.b, n, a, b, WALK_CAP, ca, cb)
+                                                 : walk_lcp(text, n, a, b, WALK_CAP);
                     if (k == WALK_CAP && k < lim) {                  // not parted yet: stays a pair, WALK_CAP deeper
                         sg[slot] = 0xffffffffu; sg[slot + 1] = 0xffffffffu;
                         return;
                     }
                     // the suffix that ends first (a proper prefix of the other) sorts first
-                    const bool mine_first = k == lim ? a > b : text[a + k] < text[b + k];
+                    const bool mine_first = k == lim ? a > b : (kp.packed ? ca < cb : text[a + k] < text[b + k]);
                     si[slot] = mine_first ? mine : other;
                     si[slot + 1] = mine_first ? other : mine;
                     sg[slot] = 0u;
@@ -1772,9 +1816,11 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
             auto wkey = [&](uint32_t mine, uint32_t ref, uint32_t d) -> uint64_t {
                 const uint64_t a = (uint64_t)mine + d, r2 = (uint64_t)ref + d;
                 const uint64_t lim = n - (a > r2 ? a : r2);
-                const uint64_t L = walk_lcp(text, n, a, r2, WALK_CAP);
+                uint32_t ca = 0, cb = 0;
+                const uint64_t L = kp.packed ? walk_lcp_packed(kp.packed, kp.b, n, a, r2, WALK_CAP, ca, cb)
+                                             : walk_lcp(text, n, a, r2, WALK_CAP);
                 if (L == WALK_CAP && L < lim) return walk_key(true, false, 0);      // agrees with the reference so far
-                const bool below = L == lim ? a > r2 : text[a + L] < text[r2 + L];
+                const bool below = L == lim ? a > r2 : (kp.packed ? ca < cb : text[a + L] < text[r2 + L]);
                 return walk_key(false, below, L);
             };
             if (act0) {
@@ -1833,9 +1879,114 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         if (!tied) SA[o] = i1;
         if ((!tied || !lt1) && !first1) LCP[o] = lcp1;
     }
-    if (CROSS && ln == 0) wl_flag[wave] = 0u;       // finished here
     SUFR_STAMP(ph__, 4)
     if (DEEP && !TIES_OUT) { SUFR_STAMP_FLUSH(2, 8) }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Windows for the finisher, cut at group heads (round 4).  Until then wave t sat on records [128 t, 128 t + 128): a group that
+// crossed the end of its window (one window in four) was re-done by a second launch that restarted at its head (CROSS), and
+// every wave first searched its records for its first group head.  Now one wave per chunk of PLAN_CH records reads the chunk's
+// keys once, takes the group heads as 34 ballot words and walks them: from a head `pos`, the window runs to the LAST head within
+// the next 128 records -- every group that starts in it ends in it --; if there is none the group at `pos` is larger than a
+// window: its head goes to the list of the next level (with its LCP against the record before it, which the finisher used to
+// write) and the walk continues at the head after it.  A chunk owns the windows and large groups that START in it; its last
+// window may reach into the next chunk (two more words of heads are read for that).
+// Two consecutive windows cover more than 128 records and a large group more than 128, so a chunk starts at most
+// 2 * PLAN_CH / 129 + 2 = 33 windows and PLAN_CH / 129 + 1 = 16 large groups (windows next to large groups may be short, but
+// then the large group's 129 records are spent): PLAN_W / PLAN_L slots per chunk, compacted by k_plan_compact after a scan.
+// ---------------------------------------------------------------------------------------------
+static constexpr uint32_t PLAN_CH = 2048, PLAN_W = 48, PLAN_L = 24;
+
+__global__ void __launch_bounds__(256)
+k_plan_windows(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ segs, const uint32_t* __restrict__ opos,
+               const uint32_t* __restrict__ segdepth, uint32_t m, int sorted_bits, int bits,
+               uint32_t* __restrict__ LCP, uint2* __restrict__ wslots, uint32_t* __restrict__ lslots,
+               uint32_t* __restrict__ wcnt, uint32_t* __restrict__ lcnt, uint32_t nchunk)
+{
+    const uint32_t chunk = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (chunk >= nchunk) return;
+    const uint32_t ln = lane_id();
+    const uint64_t c0 = (uint64_t)chunk * PLAN_CH;
+    const bool whole = sorted_bits == 0;
+    const int shift = whole ? 0 : 64 - sorted_bits;
+    // heads of [c0, c0 + 34 * 64): word `it` ends up in lane `it` of hv.  Position m counts as a head (the end of everything).
+    uint64_t hv = 0;
+    uint64_t lastk = 0; uint32_t lasts = 0;
+    if (c0 > 0) { lastk = keys[c0 - 1]; lasts = segs[c0 - 1]; }
+#pragma unroll 2
+    for (uint32_t it = 0; it < 34u; it++) {
+        const uint64_t j = c0 + 64ull * it + ln;
+        const bool valid = j < m;
+        const uint64_t k = valid ? keys[j] : 0ull;
+        const uint32_t sg = valid ? segs[j] : 0xffffffffu;
+        uint64_t pk = shfl64_up1(k); uint32_t ps = __shfl_up(sg, 1, WAVE);
+        if (ln == 0) { pk = lastk; ps = lasts; }
+        const bool head = valid ? (j == 0 || ps != sg || (!whole && (pk >> shift) != (k >> shift))) : j == m;
+        const uint64_t H = __ballot(head);
+        if (ln == it) hv = H;
+        lastk = shfl64(k, 63); lasts = __shfl(sg, 63, WAVE);
+        if (c0 + 64ull * (it + 1) > m) break;                     // (the word that holds position m is in)
+    }
+    auto word = [&](uint32_t w) -> uint64_t { return shfl64(hv, (int)w); };      // w uniform
+    // first head at or after `from` (chunk-relative), below `lim_w` words; PLAN_CH * 2 if none
+    auto next_head = [&](uint32_t from, uint32_t lim_w) -> uint32_t {
+        uint32_t w = from >> 6;
+        if (w >= lim_w) return 2u * PLAN_CH;
+        uint64_t x = word(w) & (~0ull << (from & 63u));
+        while (!x) { if (++w >= lim_w) return 2u * PLAN_CH; x = word(w); }
+        return (w << 6) + (uint32_t)__builtin_ctzll(x);
+    };
+    uint32_t nw = 0, nl = 0;
+    uint32_t pos = next_head(0, 32);
+    while (pos < PLAN_CH && c0 + pos < m) {
+        // the last head in (pos, pos + 128]
+        const uint32_t lim = pos + 128u;
+        uint32_t h = 0;
+        for (int w = (int)(lim >> 6); w >= (int)(pos >> 6) && !h; w--) {
+            uint64_t x = word((uint32_t)w);
+            if ((uint32_t)w == (lim >> 6)) x &= (lim & 63u) == 63u ? ~0ull : ((2ull << (lim & 63u)) - 1ull);
+            if ((uint32_t)w == (pos >> 6)) x &= (pos & 63u) == 63u ? 0ull : (~0ull << ((pos & 63u) + 1u));
+            if (x) h = ((uint32_t)w << 6) + 63u - (uint32_t)__builtin_clzll(x);
+        }
+        if (h) {
+            if (ln == 0 && nw < PLAN_W) wslots[(size_t)chunk * PLAN_W + nw] = make_uint2((uint32_t)(c0 + pos), h - pos);
+            nw++;
+            pos = h;
+        } else {
+            const uint32_t j = (uint32_t)(c0 + pos);
+            if (ln == 0) {
+                if (nl < PLAN_L) lslots[(size_t)chunk * PLAN_L + nl] = j;
+                // its LCP with the record before it (same segment, another group: the keys differ)
+                if (j > 0) {
+                    const uint32_t sg = segs[j];
+                    if (segs[j - 1] == sg) LCP[opos[j]] = segdepth[sg] + run_key_common(keys[j - 1], keys[j], bits);
+                }
+            }
+            nl++;
+            pos = next_head(lim + 1u, 32);
+        }
+    }
+    if (ln == 0) { wcnt[chunk] = nw < PLAN_W ? nw : PLAN_W; lcnt[chunk] = nl < PLAN_L ? nl : PLAN_L; }
+}
+
+// the chunks' slots -> dense lists: windows (start, records) and the heads of the groups above a window
+__global__ void __launch_bounds__(256)
+k_plan_compact(const uint2* __restrict__ wslots, const uint32_t* __restrict__ lslots, const uint32_t* __restrict__ wcnt,
+               const uint32_t* __restrict__ lcnt, const uint32_t* __restrict__ woff, const uint32_t* __restrict__ loff,
+               uint32_t nchunk, uint32_t* __restrict__ win_start, uint32_t* __restrict__ win_count,
+               uint32_t* __restrict__ heads)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t chunk = t / (PLAN_W + PLAN_L), slot = t % (PLAN_W + PLAN_L);
+    if (chunk >= nchunk) return;
+    if (slot < PLAN_W) {
+        if (slot < wcnt[chunk]) {
+            const uint2 w = wslots[(size_t)chunk * PLAN_W + slot];
+            win_start[woff[chunk] + slot] = w.x; win_count[woff[chunk] + slot] = w.y;
+        }
+    } else if (slot - PLAN_W < lcnt[chunk])
+        heads[loff[chunk] + slot - PLAN_W] = lslots[(size_t)chunk * PLAN_L + slot - PLAN_W];
 }
 
 // Dense level out of the tie runs that k_finish<false, true> described per window:
@@ -1924,16 +2075,14 @@ k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, RunTable R,
               const uint16_t* __restrict__ glut, const uint32_t* __restrict__ idx,
               const uint32_t* __restrict__ seg, const uint32_t* __restrict__ segdepth,
               const uint8_t* __restrict__ segperiod, uint32_t m, KeyParams kp, uint64_t* __restrict__ keys,
-              uint32_t* __restrict__ max_token_bits, int only_periodic = 0)
+              uint32_t* __restrict__ max_token_bits)
 {
     __shared__ uint16_t s_lut[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
     __syncthreads();
     uint32_t e = blockIdx.x * 256 + threadIdx.x;
     uint32_t tb = 0;
-    // only_periodic: keys[] already holds the plain-run keys of this depth (carried over by k_build_level); only the members of
-    // groups that were found periodic since take a new one
-    if (e < m && !(only_periodic && segperiod[seg[e]] == 1)) {
+    if (e < m) {
         const uint64_t k =
             make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[e] + segdepth[seg[e]], segperiod[seg[e]], kp.packed);
         keys[e] = k;
@@ -1948,6 +2097,24 @@ k_gather_keys(const uint8_t* __restrict__ text, uint64_t n, RunTable R,
     }
 }
 
+// the same for the members of the listed groups only, a workgroup per group: a level whose keys travelled with its records
+// (k_build_level) re-keys just the groups that were found periodic since
+__global__ void __launch_bounds__(256)
+k_gather_keys_listed(const uint8_t* __restrict__ text, uint64_t n, RunTable R, const uint16_t* __restrict__ glut,
+                     const uint32_t* __restrict__ idx, const uint32_t* __restrict__ list, const uint32_t* __restrict__ start,
+                     const uint32_t* __restrict__ size, const uint32_t* __restrict__ segdepth,
+                     const uint8_t* __restrict__ segperiod, KeyParams kp, uint64_t* __restrict__ keys)
+{
+    __shared__ uint16_t s_lut[256];
+    for (int i = threadIdx.x; i < 256; i += 256) s_lut[i] = glut[i];
+    __syncthreads();
+    const uint32_t g = list[blockIdx.x];
+    const uint32_t t0 = start[g], t1 = t0 + size[g];
+    const uint32_t d = segdepth[g], pi = segperiod[g];
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
+        keys[t] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[t] + d, pi, kp.packed);
+}
+
 // size of every large group (upper bound of (segment, sorted bits) in the sorted records) and the depth
 // at which its members will be re-keyed: parent depth + characters covered by the sorted bits
 template <bool DEEP>
@@ -1956,7 +2123,8 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
                const uint32_t* __restrict__ segdepth, uint32_t m, int sorted_bits, KeyParams kp,
                const uint32_t* __restrict__ heads, const uint32_t* __restrict__ idxs,
                const uint8_t* __restrict__ text, uint32_t L, uint32_t* __restrict__ sizes,
-               uint32_t* __restrict__ newdepth, uint8_t* __restrict__ newperiod, uint32_t* __restrict__ maxsize)
+               uint32_t* __restrict__ newdepth, uint8_t* __restrict__ newperiod, uint32_t* __restrict__ maxsize,
+               uint32_t* __restrict__ periodic_list = nullptr)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= L) return;
@@ -1990,7 +2158,10 @@ k_group_extent(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ s
         }
     }
     newperiod[k] = (uint8_t)pi;
-    if (pi != 1) atomicAdd(maxsize + 1, 1u);     // periodic groups of the level (rare): the high half of the 8-byte scalar
+    if (pi != 1) {                               // periodic groups of the level (rare): counted in the high half of the 8-byte scalar
+        const uint32_t at = atomicAdd(maxsize + 1, 1u);
+        if (periodic_list) periodic_list[at] = k;
+    }
     // (only a group that would raise the value: atomics on one address are served one by one in the L2)
     if (sz > __hip_atomic_load(maxsize, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxsize, sz);
 }
@@ -2142,6 +2313,61 @@ k_scan_small(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restri
 #pragma unroll
     for (int k = 0; k < SCAN1_PER; k++) { if (b0 + k < count) out[b0 + k] = run; run += v[k]; }
     if (threadIdx.x == 1023 && total) *total = (unsigned long long)run;
+}
+
+// ... and for arrays of up to SCANM_MAX values (per-cell tables of a level of a small genome, window flags): the same workgroup
+// walks the array in pieces of SCAN1_MAX with a running carry -- ~2 us per piece against two more launches of ~5 us each plus
+// the gaps between dependent dispatches
+static constexpr uint32_t SCANM_MAX = 16u * SCAN1_MAX;
+
+__global__ void __launch_bounds__(1024)
+k_scan_medium(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restrict__ out,
+              unsigned long long* __restrict__ total)
+{
+    __shared__ uint32_t s_w[2][16];
+    uint32_t carry = 0;
+    int flip = 0;
+    for (uint32_t base = 0; base < count; base += SCAN1_MAX, flip ^= 1) {
+        const uint32_t b0 = base + threadIdx.x * SCAN1_PER;
+        uint32_t v[SCAN1_PER];
+        uint32_t local = 0;
+        if (b0 + SCAN1_PER <= count) {
+#pragma unroll
+            for (int q = 0; q < SCAN1_PER / 4; q++) {
+                const uint4 a = reinterpret_cast<const uint4*>(in + b0)[q];
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
+#pragma unroll
+            for (int k = 0; k < SCAN1_PER; k++) local += v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN1_PER; k++) { v[k] = b0 + k < count ? in[b0 + k] : 0u; local += v[k]; }
+        }
+        uint32_t incl = local;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, WAVE);
+            if ((int)lane_id() >= o) incl += t;
+        }
+        if (lane_id() == 63) s_w[flip][threadIdx.x >> 6] = incl;
+        __syncthreads();                                   // (two sets of wave sums: one barrier per piece)
+        uint32_t run = carry + incl - local, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t t = s_w[flip][w]; if (w < (threadIdx.x >> 6)) run += t; all += t; }
+        carry += all;
+        if (b0 + SCAN1_PER <= count) {
+#pragma unroll
+            for (int q = 0; q < SCAN1_PER / 4; q++) {
+                uint4 a;
+                a.x = run; run += v[4 * q]; a.y = run; run += v[4 * q + 1]; a.z = run; run += v[4 * q + 2]; a.w = run; run += v[4 * q + 3];
+                reinterpret_cast<uint4*>(out + b0)[q] = a;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN1_PER; k++) { if (b0 + k < count) out[b0 + k] = run; run += v[k]; }
+        }
+    }
+    if (threadIdx.x == 0 && total) *total = (unsigned long long)carry;
 }
 
 // ---------------------------------------------------------------------------------------------
