@@ -2773,6 +2773,7 @@ k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t co
 #include "sufr_msd.inc"
 #include "sufr_part.inc"
 #include "sufr_dbl.inc"
+#include "sufr_runs.inc"
 #include "sufr_launch.inc"
 #include "sufr_wide.inc"
 #include "sufr_capi.inc"

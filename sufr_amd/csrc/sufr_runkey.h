@@ -132,11 +132,12 @@ SUFR_HD uint32_t periodic_rem(const uint8_t* __restrict__ text, uint64_t n, uint
     return rem < PERIOD_SAT ? rem : PERIOD_SAT;
 }
 
-// min(RUN_SAT, length of the run of equal bytes that starts at q), q < n; runs end at the end of the text.
+// run_len_exact: length of the run of equal bytes that starts at q, q < n; runs end at the end of the text.  run_len_at: the same,
+// saturating at RUN_SAT (what a run key can hold).
 // Genomes built with --ignore-softmask are ~50 % 'N' in runs of hundreds to millions of bytes, and the
 // reference walks through them byte by byte inside find_lcp (sufr_builder.rs:301-331).  Here a run of any
 // length costs one bitmap word, at most two more loads inside its 4 KB tile, and two for all tiles after it.
-SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
+SUFR_HD uint64_t run_len_exact(uint64_t q, RunTable rt)
 {
     uint64_t w = q >> 6;
     uint64_t m = rt.ends[w] & (~0ull << (q & 63u));
@@ -148,13 +149,16 @@ SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
             w = (tile << 6) + (uint64_t)__builtin_ctzll(later);
             m = rt.ends[w];
         } else {
-            if (tile + 1 >= rt.ntiles) return RUN_SAT;                     // cannot happen: n-1 is a run end
+            if (tile + 1 >= rt.ntiles) return ~0ull;                       // cannot happen: n-1 is a run end
             const uint32_t fe = rt.first_end[rt.next_tile[tile + 1]];
-            const uint64_t len = (uint64_t)fe - q + 1;
-            return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
+            return (uint64_t)fe - q + 1;
         }
     }
-    const uint64_t len = (w << 6) + (uint64_t)__builtin_ctzll(m) - q + 1;
+    return (w << 6) + (uint64_t)__builtin_ctzll(m) - q + 1;
+}
+SUFR_HD uint32_t run_len_at(uint64_t q, RunTable rt)
+{
+    const uint64_t len = run_len_exact(q, rt);
     return len < RUN_SAT ? (uint32_t)len : RUN_SAT;
 }
 

@@ -359,6 +359,92 @@ def test_allow_ambiguity_runs_beyond_2_pow_16_bytes(ctx):
     assert int(lcp.max()) >= 299_990
 
 
+def _runs_text(seed, n, symbol, nruns, lo, hi, extra=()):
+    """random ACGT with `nruns` runs of `symbol` (lengths uniform in [lo, hi)) and the runs of `extra` lengths, '$'-terminated"""
+    rng = np.random.default_rng(seed)
+    body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    lens = np.concatenate([rng.integers(lo, hi, nruns), np.asarray(extra, dtype=np.int64)]).astype(np.int64)
+    rng.shuffle(lens)
+    gap = (n - int(lens.sum())) // (lens.size + 1)
+    assert gap >= 2
+    at = 0
+    for ln in lens.tolist():
+        at += int(rng.integers(1, 2 * gap - 1))
+        body[at:at + ln] = symbol
+        at += ln
+    return np.concatenate([body[:max(at + 5, n // 2)], np.frombuffer(b"$", dtype=np.uint8)])
+
+
+@pytest.mark.parametrize("case", ["n_runs_amb", "g_runs_plain", "n_runs_amb_soft", "two_symbols", "n_runs_amb_3_shards"])
+def test_buckets_of_one_repeated_symbol_equal_oracle(oracle, case):
+    """A bucket c^21 of a million records and more is ordered in closed form (sufr_runs.inc): only the last member of every run
+    goes through the levels, the others are placed by counting -- class 0 / class 1 blocks, the table of levels and the
+    rectangles of the ~2 000 longest runs, the LCP inside a tile, across tiles, across blocks and across the two classes.
+    Runs stay below 1 000 symbols so that the reference algorithm (byte walks) is the checker: whole arrays equal."""
+    kw = dict(is_dna=True)
+    if case in ("n_runs_amb", "n_runs_amb_3_shards"):
+        raw = _runs_text(51, 6_000_000, ord("N"), 7000, 21, 900); kw["allow_ambiguity"] = True
+    elif case == "g_runs_plain":
+        raw = _runs_text(52, 5_000_000, ord("G"), 5000, 18, 700)
+    elif case == "n_runs_amb_soft":
+        raw = _runs_text(53, 5_000_000, ord("a"), 6000, 25, 800); kw["allow_ambiguity"] = True; kw["ignore_softmask"] = True
+    else:
+        raw = _runs_text(54, 7_000_000, ord("T"), 5000, 21, 600)
+        rng = np.random.default_rng(540)
+        for _ in range(4500):                                     # a second symbol's runs in the gaps where they fit
+            ln = int(rng.integers(21, 650)); at = int(rng.integers(0, raw.size - 700))
+            if not (raw[at - 1:at + ln + 1] == ord("T")).any():
+                raw[at:at + ln] = ord("C")
+    soft = kw.pop("ignore_softmask", False)
+    norm = oracle.normalize(raw, soft)
+    osa, olcp, _ = oracle.build(norm, threads=min(32, os.cpu_count() or 1), **kw)
+    db = sufr_amd.DeviceBuilder(0)
+    x = torch.from_numpy(raw).cuda()
+    if case.endswith("3_shards"):
+        gsa, glcp, _ = _sharded_arrays(db, x, x.numel(), 3, raw_text=True, ignore_softmask=soft, **kw)
+    else:
+        sa, lcp = db.sort(x, raw_text=True, ignore_softmask=soft, **kw)
+        gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    db.close()
+    bad = np.nonzero(gsa != osa)[0]
+    assert bad.size == 0, f"SA differs at rank {bad[0]} of {osa.size}: got {gsa[bad[0]]} want {osa[bad[0]]}"
+    bad = np.nonzero(glcp != olcp)[0]
+    assert bad.size == 0, f"LCP differs at rank {bad[0]} of {osa.size}: got {glcp[bad[0]]} want {olcp[bad[0]]} (SA {gsa[bad[0] - 1]}, {gsa[bad[0]]})"
+
+
+@pytest.mark.parametrize("case", ["long_n_runs", "all_a", "one_class"])
+def test_buckets_of_one_repeated_symbol_with_very_long_runs_are_exact(case):
+    """Runs of 10^5 - 10^6 symbols (the rectangles above the table; one run of 3 * 10^6 'A' is a single rectangle): the byte-walking
+    reference cannot check these in reasonable time; an exact run-walking comparison of sampled adjacent ranks does, inside the
+    bucket densely."""
+    rng = np.random.default_rng(77)
+    kw = dict(is_dna=True)
+    if case == "long_n_runs":
+        raw = _runs_text(61, 9_000_000, ord("N"), 2500, 21, 3000, extra=(1_500_000, 1_100_000, 300_000, 299_999, 70_000, 70_001, 5000))
+        kw["allow_ambiguity"] = True
+    elif case == "all_a":
+        raw = np.concatenate([np.full(3_000_000, ord("A"), np.uint8), np.frombuffer(b"$", dtype=np.uint8)])
+    else:                                                          # every run of T is followed by a smaller symbol: one class only
+        raw = _runs_text(62, 6_000_000, ord("T"), 3000, 21, 1500, extra=(400_000, 90_000))
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(torch.from_numpy(raw).cuda(), raw_text=True, **kw)
+    sa = sa.cpu().numpy().view(np.uint32).astype(np.int64); lcp = lcp.cpu().numpy().view(np.uint32).astype(np.int64)
+    db.close()
+    elig = np.ones(raw.size, bool) if kw.get("allow_ambiguity") else np.isin(raw, np.frombuffer(b"ACGT$", dtype=np.uint8))
+    assert sa.size == int(elig.sum()) and np.array_equal(np.sort(sa), np.flatnonzero(elig))
+    change = np.flatnonzero(raw[1:] != raw[:-1]) + 1
+    starts = np.concatenate([[0], change, [raw.size]])
+    sym = {"long_n_runs": ord("N"), "all_a": ord("A"), "one_class": ord("T")}[case]
+    inside = np.flatnonzero((raw[sa] == sym) & (lcp >= 21))       # ranks of the bucket (and a few of its neighbours)
+    ranks = np.concatenate([rng.integers(1, sa.size, 15_000), inside[rng.integers(0, inside.size, 45_000)],
+                            inside[:50], inside[-50:]])
+    for r in ranks.tolist():
+        if r == 0:
+            continue
+        k, less = _rle_lcp_and_order(raw, starts, int(sa[r - 1]), int(sa[r]))
+        assert less and lcp[r] == k, (case, r, int(sa[r - 1]), int(sa[r]), k, int(lcp[r]))
+
+
 @pytest.mark.parametrize("kind", ["all_a", "acgt_k", "fib", "two_identical", "n_run", "tandem"])
 @pytest.mark.parametrize("n", [100, 5000])
 def test_adversarial_micro_inputs(ctx, oracle, kind, n):
