@@ -2111,7 +2111,8 @@ k_gather_keys_listed(const uint8_t* __restrict__ text, uint64_t n, RunTable R, c
     const uint32_t g = list[blockIdx.x];
     const uint32_t t0 = start[g], t1 = t0 + size[g];
     const uint32_t d = segdepth[g], pi = segperiod[g];
-    for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
+    // (gridDim.y workgroups share a group: a tandem array's tie run is 10^4-10^5 members whose periodic extensions are walked)
+    for (uint32_t t = t0 + blockIdx.y * 256u + threadIdx.x; t < t1; t += 256u * gridDim.y)
         keys[t] = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)idx[t] + d, pi, kp.packed);
 }
 

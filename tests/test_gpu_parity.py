@@ -412,6 +412,48 @@ def test_buckets_of_one_repeated_symbol_equal_oracle(oracle, case):
     assert bad.size == 0, f"LCP differs at rank {bad[0]} of {osa.size}: got {glcp[bad[0]]} want {olcp[bad[0]]} (SA {gsa[bad[0] - 1]}, {gsa[bad[0]]})"
 
 
+def test_run_bucket_of_a_protein_text_equals_oracle(oracle):
+    """masked protein: runs of X in a 20-letter text (5 bits per symbol, 12 symbols per key, no packed stream: the bucket X^12 is
+    found among the left-over buckets of the last MSD level, not after the first)"""
+    rng = np.random.default_rng(88)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    n = 5_000_000
+    t = aa[rng.integers(0, 20, n)].copy()
+    at = 0
+    while at < n - 2000:
+        at += int(rng.integers(50, 1500)); ln = int(rng.integers(12, 900))
+        t[at:at + ln] = ord("X"); at += ln
+    t[np.arange(700, n, 50_000)] = ord("%")
+    t[-1] = ord("$")
+    norm = oracle.normalize(t, False)
+    osa, olcp, _ = oracle.build(norm, is_dna=False, threads=min(32, os.cpu_count() or 1))
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(torch.from_numpy(t).cuda(), is_dna=False, raw_text=True)
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    db.close()
+    assert np.array_equal(gsa, osa) and np.array_equal(glcp, olcp)
+
+
+@pytest.mark.parametrize("L", [7, 30, 400])
+def test_max_query_len_on_a_text_with_a_run_bucket(L):
+    """-m L after the closed-form bucket: the capped build is the canonical member of the reference's family (LCP = min(LCP, L),
+    ties in descending position, the same first L characters rank by rank) of the uncapped one"""
+    raw = _runs_text(71, 5_000_000, ord("N"), 6000, 21, 900)
+    db = sufr_amd.DeviceBuilder(0)
+    x = torch.from_numpy(raw).cuda()
+    fsa, flcp = db.sort(x, is_dna=True, allow_ambiguity=True, raw_text=True)
+    fsa = fsa.cpu().numpy().view(np.uint32).astype(np.int64); flcp = flcp.cpu().numpy().view(np.uint32).astype(np.int64)
+    sa, lcp = db.sort(x, is_dna=True, allow_ambiguity=True, raw_text=True, max_query_len=L)
+    sa = sa.cpu().numpy().view(np.uint32).astype(np.int64); lcp = lcp.cpu().numpy().view(np.uint32).astype(np.int64)
+    db.close()
+    assert np.array_equal(np.sort(sa), np.sort(fsa))
+    assert np.array_equal(lcp, np.minimum(flcp, L))
+    tie = lcp >= L
+    assert np.all(sa[1:][tie[1:]] < sa[:-1][tie[1:]]), "ties must come in descending position"
+    W = min(L, 48)
+    assert np.array_equal(_first_chars(raw, sa, W), _first_chars(raw, fsa, W))
+
+
 @pytest.mark.parametrize("case", ["long_n_runs", "all_a", "one_class"])
 def test_buckets_of_one_repeated_symbol_with_very_long_runs_are_exact(case):
     """Runs of 10^5 - 10^6 symbols (the rectangles above the table; one run of 3 * 10^6 'A' is a single rectangle): the byte-walking

@@ -161,6 +161,32 @@ def test_medium_windowed_build_properties():
     db.close()
 
 
+def test_run_buckets_inside_windows_equal_the_single_build_and_the_oracle(oracle):
+    """--allow-ambiguity text whose N bucket is ordered in closed form (sufr_runs.inc: 2-3 M records per window), built in two
+    windows: N runs cross the cut and sit in the margin, whose suffixes are dropped afterwards; merged arrays = the one-window
+    arrays = the oracle's (runs stay below 1 000 symbols so that the byte-walking reference is the checker)"""
+    rng = np.random.default_rng(23)
+    n = 44_000_000
+    t = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    at = 0
+    while at < n - 3000:
+        at += int(rng.integers(200, 6000)); ln = int(rng.integers(21, 950))
+        t[at:at + ln] = ord("N"); at += ln
+    t[n // 2 - 300:n // 2 + 400] = ord("N")                     # one run across the cut
+    t[-1] = ord("$")
+    x = torch.from_numpy(t).cuda()
+    flags = dict(is_dna=True, allow_ambiguity=True)
+    db = sufr_amd.DeviceBuilder(0)
+    one_sa, one_lcp = db.sort(x, **flags)
+    one_sa = one_sa.cpu().numpy().view(np.uint32).astype(np.uint64); one_lcp = one_lcp.cpu().numpy().view(np.uint32).astype(np.uint64)
+    db.close()
+    sa, lcp, st = build(x, n // 2, 1 << 20, 8, **flags)
+    assert np.array_equal(sa, one_sa) and np.array_equal(lcp, one_lcp)
+    import os
+    want_sa, want_lcp, _ = oracle.build(t, threads=min(32, os.cpu_count() or 1), **flags)
+    assert np.array_equal(one_sa, want_sa.astype(np.uint64)) and np.array_equal(one_lcp, want_lcp.astype(np.uint64))
+
+
 def test_text_beyond_32_bits():
     """4.4e9 bytes (> 2^32): random DNA with repeats planted across the window boundary, u64 arrays.  Checked without a
     second build: SA is a permutation of the suffix starts, sampled neighbours are in order with the exact LCP."""
