@@ -76,8 +76,11 @@ typedef struct sufr_hip_stats {
                                    alphabets: k_msd_hist_text / k_hist_text) */
     float ms_partition;         /* k_msd_part_text / k_scatter_text: THE radix-partition kernel (one launch) */
     float ms_passes;            /* further MSD levels + leaf sorts */
-    float ms_finish;            /* k_finish of the top level */
-    float ms_deep;              /* all deeper levels */
+    float ms_finish;            /* boundary LCPs of the leaf windows + tie counts (k_fix_window_lcp, k_tie_counts) */
+    float ms_deep;              /* everything below the MSD levels: left-over buckets and tie runs through the re-keying levels
+                                   (k_gather_keys, k_group_sort_*, k_plan_windows, k_finish, prefix doubling) and the buckets of one
+                                   repeated symbol placed by counting (sufr_runs.inc); their records are in deep_records only as far as
+                                   they went through the levels */
     /* host phases of sufr_hip_create_file (seconds; 0 from the other entry points) */
     float host_read_s;          /* sequence file -> text */
     float host_build_s;         /* H2D + device build (+ first-use allocations) */
