@@ -1,16 +1,18 @@
 // sufr_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for suffix-array + LCP construction.
 //
 // Replaces the CPU hot loops of the reference builder (libsufr/src/sufr_builder.rs):
-//   * text normalisation            (143-160)  -> k_normalize_pack_dna / k_normalize_bytehist (+ run-end
-//                                                 tables, bit-packed code stream)
+//   * text normalisation            (143-160)  -> k_text_pass_dna / k_normalize_bytehist (+ run-end tables, bit-packed
+//                                                 code stream, suffix-start bitmap, first-digit histogram)
 //   * eligibility + upper_bound/is_less/find_lcp bucketing (346-394, 442-462)
 //                                              -> MSD partition levels on packed k-character prefix keys
-//                                                 (sufr_msd.inc: k_msd_part_text, k_msd_scatter; alphabets without
-//                                                 a packed stream: k_hist_text + k_scatter_text here)
+//                                                 (sufr_part.inc: k_msd_part_text; sufr_msd.inc: k_msd_scatter; alphabets
+//                                                 without a packed stream: k_hist_text + k_scatter_text here)
 //   * merge_sort / merge            (601-767)  -> k_leaf_sort (sufr_msd.inc: in-LDS sort of a bucket, SA, LCP from
-//                                                 the key xor) + the tie / re-keying levels here (k_gather_keys,
-//                                                 k_hist_pairs / k_scatter_pairs, k_finish: wave-level tie
-//                                                 refinement, exact LCP) + prefix doubling (sufr_dbl.inc)
+//                                                 the key xor) + the tie / re-keying levels here (k_gather_keys, the
+//                                                 group sorts of sufr_msd.inc, k_plan_windows + k_finish: wave-level tie
+//                                                 refinement, exact LCP) + prefix doubling (sufr_dbl.inc) + buckets of one
+//                                                 repeated symbol placed by counting (sufr_runs.inc; find_lcp's byte walk
+//                                                 through a run, 319-329, never happens)
 //   * boundary LCP of write()       (886-906)  -> LCP at every group / window / shard boundary (key xor,
 //                                                 k_fix_window_lcp, k_lcp_pair)
 //
