@@ -375,7 +375,30 @@ def _runs_text(seed, n, symbol, nruns, lo, hi, extra=()):
     return np.concatenate([body[:max(at + 5, n // 2)], np.frombuffer(b"$", dtype=np.uint8)])
 
 
-@pytest.mark.parametrize("case", ["n_runs_amb", "g_runs_plain", "n_runs_amb_soft", "two_symbols", "n_runs_amb_3_shards"])
+def _templated_runs_text(seed, nruns, lo, hi, ntemplates=40, tlen=260):
+    """runs of N whose TAILS come from a few templates (long tail LCPs: the order of two runs is decided hundreds of symbols behind
+    them; many runs share a tail up to a late mutation), some runs back to back with one symbol between them, one at the very
+    start of the text and one right before the final '$'"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    templates = [acgt[rng.integers(0, 4, tlen)] for _ in range(ntemplates)]
+    parts = [np.full(int(rng.integers(lo, hi)), ord("N"), np.uint8)]          # a run at position 0
+    for k in range(nruns):
+        t = templates[int(rng.integers(0, ntemplates))].copy()
+        if rng.random() < 0.7:                                               # a late mutation, or none at all
+            t[int(rng.integers(tlen // 2, tlen))] = acgt[int(rng.integers(0, 4))]
+        cut = tlen if rng.random() < 0.8 else int(rng.integers(1, tlen))     # some tails are cut short by the next run
+        parts.append(t[:cut])
+        if rng.random() < 0.05:
+            parts.append(acgt[rng.integers(0, 4, int(rng.integers(300, 3000)))])
+        parts.append(np.full(int(rng.integers(lo, hi)), ord("N"), np.uint8))
+        if rng.random() < 0.03:                                              # two runs with ONE symbol between them
+            parts.append(acgt[rng.integers(0, 4, 1)]); parts.append(np.full(int(rng.integers(lo, hi)), ord("N"), np.uint8))
+    parts.append(np.frombuffer(b"$", dtype=np.uint8))                        # the last run ends at the end of the text
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("case", ["n_runs_amb", "g_runs_plain", "n_runs_amb_soft", "two_symbols", "n_runs_amb_3_shards", "templated_tails"])
 def test_buckets_of_one_repeated_symbol_equal_oracle(oracle, case):
     """A bucket c^21 of a million records and more is ordered in closed form (sufr_runs.inc): only the last member of every run
     goes through the levels, the others are placed by counting -- class 0 / class 1 blocks, the table of levels and the
@@ -384,6 +407,8 @@ def test_buckets_of_one_repeated_symbol_equal_oracle(oracle, case):
     kw = dict(is_dna=True)
     if case in ("n_runs_amb", "n_runs_amb_3_shards"):
         raw = _runs_text(51, 6_000_000, ord("N"), 7000, 21, 900); kw["allow_ambiguity"] = True
+    elif case == "templated_tails":
+        raw = _templated_runs_text(55, 5200, 6, 760); kw["allow_ambiguity"] = True
     elif case == "g_runs_plain":
         raw = _runs_text(52, 5_000_000, ord("G"), 5000, 18, 700)
     elif case == "n_runs_amb_soft":
