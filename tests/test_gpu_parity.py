@@ -479,6 +479,26 @@ def test_max_query_len_on_a_text_with_a_run_bucket(L):
     assert np.array_equal(_first_chars(raw, sa, W), _first_chars(raw, fsa, W))
 
 
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_stalling_repeats_over_shards_equal_oracle(oracle, shards):
+    """Thousands of copies of three 300-symbol templates: the re-keying levels stop shrinking and, on one GPU, prefix doubling takes
+    over -- it keys a suffix by the RANK of a later position, which exists only if every suffix of the text is in the build.  A
+    shard holds its own first-digit range only: there the build must stay with the levels (round 4's soak found 38 000 wrong ranks
+    in such a text over two shards, and a memory fault)."""
+    raw = _templated_runs_text(9, 6000, 6, 700, ntemplates=3, tlen=300)
+    kw = dict(is_dna=True, allow_ambiguity=True)
+    osa, olcp, _ = oracle.build(oracle.normalize(raw, False), threads=min(32, os.cpu_count() or 1), **kw)
+    db = sufr_amd.DeviceBuilder(0)
+    x = torch.from_numpy(raw).cuda()
+    if shards == 1:
+        sa, lcp = db.sort(x, raw_text=True, **kw)
+        gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    else:
+        gsa, glcp, _ = _sharded_arrays(db, x, x.numel(), shards, raw_text=True, **kw)
+    db.close()
+    assert np.array_equal(gsa, osa) and np.array_equal(glcp, olcp)
+
+
 @pytest.mark.parametrize("case", ["long_n_runs", "all_a", "one_class"])
 def test_buckets_of_one_repeated_symbol_with_very_long_runs_are_exact(case):
     """Runs of 10^5 - 10^6 symbols (the rectangles above the table; one run of 3 * 10^6 'A' is a single rectangle): the byte-walking
