@@ -1,15 +1,18 @@
 """Soak of the per-group sort of the re-keying levels against the CPU checker:   python profiles/soak_families.py [minutes] [seed]
 Texts of 2 - 6 Mb with high-copy repeat families (tie groups of every size class: windows of small groups, groups above
 4 096 records, groups above 16 384) plus homopolymer / tandem stretches and N runs, built through the host ABI with random
-flags and, every third text, in forced windows or with --max-query-len.  (Test-side tooling, like soak.py.)"""
+flags and, in turn, plainly, in forced windows, with --max-query-len, or over 2 - 5 shards through the device ABI with the
+first LCPs stitched on the device.  (Test-side tooling, like soak.py.)"""
 import os
 import sys
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import torch
 import sufr_amd
 from oracle_helper import Oracle
+from test_gpu_parity import _sharded_arrays
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) % 100000
@@ -48,8 +51,20 @@ while time.time() < t_end:
         want_sa, want_lcp, _ = oracle.build(raw, is_dna=True, allow_ambiguity=amb, threads=8)
     except RuntimeError:
         continue
-    mode = cases % 3
+    mode = cases % 4
     try:
+        if mode == 3:                                           # shards of the device ABI, concatenated
+            shards = int(rng.integers(2, 6))
+            db = sufr_amd.DeviceBuilder(0)
+            x = torch.from_numpy(raw).cuda()
+            gsa, glcp, _ = _sharded_arrays(db, x, x.numel(), shards, is_dna=True, allow_ambiguity=amb)
+            db.close()
+            ok = np.array_equal(gsa.astype(np.int64), want_sa.astype(np.int64)) and np.array_equal(glcp.astype(np.int64), want_lcp.astype(np.int64))
+            if not ok:
+                fails += 1
+                print(f"FAIL {ctxt} mode={mode} shards={shards}", flush=True)
+            print(f"case {cases} mode {mode} shards={shards} {'ok' if ok else 'FAIL'}", flush=True)
+            continue
         if mode == 1:
             ctx.set_window(int(rng.integers(raw.size // 6, raw.size)), int(rng.choice([64, 5000, 200000])))
         L = int(rng.choice([8, 16, 40])) if mode == 2 else None
