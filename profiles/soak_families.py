@@ -57,7 +57,11 @@ while time.time() < t_end:
             shards = int(rng.integers(2, 6))
             db = sufr_amd.DeviceBuilder(0)
             x = torch.from_numpy(raw).cuda()
-            gsa, glcp, _ = _sharded_arrays(db, x, x.numel(), shards, is_dna=True, allow_ambiguity=amb)
+            Lq = int(rng.choice([8, 16, 40])) if rng.random() < 0.3 else None     # capped: against the one-GPU build of the same cap
+            gsa, glcp, _ = _sharded_arrays(db, x, x.numel(), shards, is_dna=True, allow_ambiguity=amb, max_query_len=Lq)
+            if Lq is not None:
+                one_sa, one_lcp = db.sort(x, is_dna=True, allow_ambiguity=amb, max_query_len=Lq)
+                want_sa = one_sa.cpu().numpy().view(np.uint32); want_lcp = one_lcp.cpu().numpy().view(np.uint32)
             db.close()
             ok = np.array_equal(gsa.astype(np.int64), want_sa.astype(np.int64)) and np.array_equal(glcp.astype(np.int64), want_lcp.astype(np.int64))
             if not ok:
