@@ -479,6 +479,29 @@ def test_max_query_len_on_a_text_with_a_run_bucket(L):
     assert np.array_equal(_first_chars(raw, sa, W), _first_chars(raw, fsa, W))
 
 
+@pytest.mark.parametrize("letters", [b"AC", b"ACDEFGHIKLMN"])
+def test_run_buckets_in_2_and_4_bit_alphabets_equal_oracle(oracle, letters):
+    """the closed form with first digits of 7 symbols (2-bit codes) and of 3 symbols (4-bit codes): a generic alphabet, not the DNA
+    table; the repeated symbol is the largest letter (every run is followed by a smaller one or the end: one class) or a middle
+    one (both classes)"""
+    rng = np.random.default_rng(len(letters))
+    al = np.frombuffer(letters, dtype=np.uint8)
+    n = 5_000_000
+    t = al[rng.integers(0, al.size, n)].copy()
+    sym = int(al[-1]) if al.size == 2 else int(al[al.size // 2])
+    at = 0
+    while at < n - 2000:
+        at += int(rng.integers(30, 1200)); ln = int(rng.integers(8, 900))
+        t[at:at + ln] = sym; at += ln
+    t[-1] = ord("$")
+    osa, olcp, _ = oracle.build(t, is_dna=False, threads=min(32, os.cpu_count() or 1))
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(torch.from_numpy(t).cuda(), is_dna=False)
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    db.close()
+    assert np.array_equal(gsa, osa) and np.array_equal(glcp, olcp)
+
+
 @pytest.mark.parametrize("shards", [1, 2, 3])
 def test_stalling_repeats_over_shards_equal_oracle(oracle, shards):
     """Thousands of copies of three 300-symbol templates: the re-keying levels stop shrinking and, on one GPU, prefix doubling takes
