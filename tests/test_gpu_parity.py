@@ -138,6 +138,25 @@ def test_multi_device_create_5mb_genome(tmp_path, oracle):
     assert one.read_bytes() == ref.read_bytes()
 
 
+def test_multi_device_create_with_a_run_bucket_and_stalling_repeats(tmp_path, oracle):
+    """`sufr create --allow-ambiguity` over 1, 2 and 3 contexts on a text whose N bucket goes through the closed form and whose
+    templated repeats hand a level to prefix doubling (in every shard since round 4): the files are byte-identical, and equal to
+    the oracle's"""
+    raw = _templated_runs_text(12, 5000, 6, 700, ntemplates=4, tlen=280)
+    fa = tmp_path / "r.fa"
+    with open(fa, "wb") as f:
+        f.write(b">one\n" + raw[:-1].tobytes() + b"\n")
+    one = tmp_path / "one.sufr"
+    sufr_amd.create(str(fa), str(one), is_dna=True, allow_ambiguity=True)
+    for k in (2, 3):
+        out = tmp_path / f"k{k}.sufr"
+        sufr_amd.create(str(fa), str(out), is_dna=True, allow_ambiguity=True, devices=[0] * k)
+        assert out.read_bytes() == one.read_bytes(), k
+    ref = tmp_path / "ref.sufr"
+    oracle.create(str(fa), str(ref), is_dna=True, allow_ambiguity=True)
+    assert one.read_bytes() == ref.read_bytes()
+
+
 def test_create_reports_an_unwritable_output(tmp_path):
     """"{filename}: {io error}" like SufrBuilder::write (sufr_builder.rs:820), exit code 1 from the binary"""
     bad = tmp_path / "no_such_dir" / "x.sufr"
