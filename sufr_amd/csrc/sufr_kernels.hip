@@ -2678,6 +2678,38 @@ k_mask_lcp_staged(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* 
     lcp[r] = c;
 }
 
+// The same count read off the SORTED KEYS (round 4): the key of a rank holds its first `cnt0` care symbols as codes from the top
+// (k_mask_keys*: equal codes <=> equal bytes, 0 past the end of the text), so two neighbours part where their keys do -- a
+// streaming pass over keys and positions instead of a random sector per rank (hu-mask on the 3.1 Gb stand-in: 96 -> 8 ms).
+// A mask of more care symbols than a key holds continues in the text for the pairs whose keys are equal; a pair with a
+// position within `span` of the end of the text counts symbol by symbol as before (past-the-end codes are equal, but do not count).
+__global__ void __launch_bounds__(256)
+k_mask_lcp_keys(const uint8_t* __restrict__ text, uint64_t n, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sa,
+                uint32_t s, const uint32_t* __restrict__ offs, uint32_t weight, uint32_t cnt0, int b, uint32_t span,
+                uint32_t* __restrict__ lcp)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= s) return;
+    uint32_t c = 0;
+    if (r > 0) {
+        const uint64_t a = sa[r - 1], p = sa[r];
+        if ((a > p ? a : p) + span <= n) {
+            const uint64_t x = keys[r - 1] ^ keys[r];
+            c = x ? div_by_bits((uint32_t)__builtin_clzll(x), b) : cnt0;
+            if (c > cnt0) c = cnt0;
+            if (c == cnt0)
+                while (c < weight && text[a + offs[c]] == text[p + offs[c]]) c++;
+        } else {
+            while (c < weight) {
+                const uint64_t qa = a + offs[c], qb = p + offs[c];
+                if (qa >= n || qb >= n || text[qa] != text[qb]) break;
+                c++;
+            }
+        }
+    }
+    lcp[r] = c;
+}
+
 // Exact LCP of two suffixes of the device text: find_lcp(a, b, text_len, 0) of write()'s boundary fix
 // (sufr_builder.rs:893-902), for the first record of a shard against the last record of the shard before it.
 // One workgroup, 4096 characters per round.
