@@ -2548,13 +2548,17 @@ k_elig_emit_desc(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
 {
     __shared__ uint16_t s_lut[256];
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_pos[TILE];                          // the tile's eligible positions in text order
     s_lut[threadIdx.x] = glut[threadIdx.x];
     __syncthreads();
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * 16;
+    uint8_t v[16];
+    if (p0 + 16 <= n) *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(text + p0);
+    else for (int e = 0; e < 16; e++) v[e] = p0 + e < n ? text[p0 + e] : 0;
     uint32_t el = 0, cnt = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        if (p0 + e < n && (s_lut[text[p0 + e]] & 0x8000u) && mask_in_shard(text, n, s_lut, p0 + e, ms)) { el |= 1u << e; cnt++; }
+        if (p0 + e < n && (s_lut[v[e]] & 0x8000u) && mask_in_shard(text, n, s_lut, p0 + e, ms)) { el |= 1u << e; cnt++; }
     uint32_t incl = cnt;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -2563,11 +2567,16 @@ k_elig_emit_desc(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* _
     }
     if (lane_id() == 63) s_w[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t r = tileoff[blockIdx.x] + incl - cnt;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) r += s_w[w];
+    uint32_t q = incl - cnt;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) q += s_w[w];
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        if (el & (1u << e)) { idx[s - 1u - r] = (uint32_t)(p0 + e); r++; }
+        if (el & (1u << e)) s_pos[q++] = (uint32_t)(p0 + e);
+    __syncthreads();
+    // out in DESCENDING position: consecutive lanes, consecutive (descending) places -- whole lines instead of one line per lane
+    // and store (round 3's version: 14.9 ms for the 2.95 G positions of the stand-in)
+    const uint32_t total = s_w[0] + s_w[1] + s_w[2] + s_w[3], base = tileoff[blockIdx.x];
+    for (uint32_t j = threadIdx.x; j < total; j += 256) idx[s - 1u - (base + j)] = s_pos[j];
 }
 
 // key of one block of care characters: code of text[pos + offs[k]] (0 past the end), first one highest
