@@ -16,6 +16,12 @@ prefix-bucket range: every rank holds the text, derives the same splitters from 
 histogram and builds only its bucket range; the only exchange is an all_gather of
 {first suffix, last suffix, count} per rank for the boundary-LCP stitch (sufr_builder.rs:893-902).
 Total work is fixed as N grows => "scaling": "strong".  value = suffixes of the whole genome / time.
+`python bench.py --gpus N` outside torch.distributed.run starts its N ranks itself (a child `python -m
+torch.distributed.run --nproc-per-node N bench.py ...`; the parent never touches the GPU).  On a one-GPU box the N > 1 leg
+runs as `--gpus 2 --backend gloo --share-device` (two ranks, one device, host-side exchange) and, with
+SUFR_BENCH_FORCE_DIST=1 at N = 1, through RCCL itself: nccl is initialised at world size 1, the rank builds TWO first-digit
+shards one after the other and every step runs the all_gather on device tensors + sufr_hip_stitch_device_u32 on the
+context's stream exactly as a rank of an N-GPU job does.
 
 Prints ONE JSON line on rank 0.
 """
@@ -57,11 +63,21 @@ def pmc_traffic_bytes(workload: str):
     for 16-B/lane streaming reads on gfx950, WRITE_SIZE as read).  None when no profile exists."""
     import csv
     import glob
+    import hashlib
     files = sorted(glob.glob(str(ROOT / "profiles" / f"r*_pmc_{workload}.csv")))
     if not files:
         return None, None
+    # the counters belong to ONE version of the kernel: the summary's first line names the sha256 of sufr_part.inc it was
+    # collected from (profiles/summarize_pmc.py); a different source means a stale figure -> null and a loud line
+    lines = open(files[-1]).read().splitlines()
+    have = hashlib.sha256((ROOT / "sufr_amd" / "csrc" / "sufr_part.inc").read_bytes()).hexdigest()
+    tagged = lines[0].split("sha256=")[-1].strip() if lines and lines[0].startswith("#") else None
+    if tagged != have:
+        print(f"bench.py: roofline.traffic is null: {Path(files[-1]).name} was collected from "
+              f"{'an untagged' if tagged is None else 'another'} version of sufr_part.inc (re-run profiles/pmc.sh)", file=sys.stderr)
+        return None, None
     fetch = write = None
-    for r in csv.DictReader(open(files[-1])):
+    for r in csv.DictReader(ln for ln in lines if not ln.startswith("#")):
         if "k_msd_part_text" in r["kernel"] or "k_scatter_text" in r["kernel"]:
             if r["counter"] == "FETCH_SIZE":
                 fetch = float(r["largest_dispatch_value"])
@@ -72,9 +88,15 @@ def pmc_traffic_bytes(workload: str):
     return (2.0 * fetch + write) * 1024.0, "profiles/" + Path(files[-1]).name
 
 
-def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: float = 15.0):
+def host_memory_gb() -> float:
+    return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
+
+
+def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: float = 15.0, full_text=None):
     """The oracle (C restatement of the reference algorithm, kind = "port") timed on this box's host
-    cores on a bounded prefix of the same workload."""
+    cores: a bounded prefix of the workload swept over thread counts and -- when the host can hold it (`full_text`
+    is a callable that returns the whole text; the caller checks memory and cores) -- ONE run on the whole workload at
+    the sweep's best thread count, which then is `value` (the 6 % prefix flattered the CPU)."""
     sys.path.insert(0, str(ROOT / "tests"))
     from oracle_helper import Oracle
     try:
@@ -106,13 +128,31 @@ def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: f
         if best is None or s / dt > best[0]:
             best = (s / dt, t, s, dt, st)
     rate, bt, s, dt, st = best
-    return {"value": rate, "unit": "suffixes/s", "cores": bt, "best_threads": bt, "host_cores": cores, "kind": "port",
-            "threads_sweep": sweep,
-            "sample": f"first {nb} bases of the same text (+'$'), {s} suffixes, {partitions} partitions; best of the sweep: "
-                      f"{bt} threads, {dt:.2f} s wall (partition {st.t_partition:.2f} s, sort {st.t_sort:.2f} s)"}
+    sweep_note = (f"first {nb} bases of the same text (+'$'), {s} suffixes, {partitions} partitions; best of the sweep: "
+                  f"{bt} threads, {dt:.2f} s wall (partition {st.t_partition:.2f} s, sort {st.t_sort:.2f} s)")
+    out = {"value": rate, "unit": "suffixes/s", "cores": bt, "best_threads": bt, "host_cores": cores, "kind": "port",
+           "threads_sweep": sweep, "sample": sweep_note, "sample_only": True}
+    if full_text is not None:
+        try:
+            whole = full_text()
+            norm = o.normalize(whole, flags.get("ignore_softmask", False))
+            del whole
+            t0 = time.perf_counter()
+            _, _, fst = o.build(norm, is_dna=flags.get("is_dna", False), num_partitions=partitions, threads=bt)
+            fdt = time.perf_counter() - t0
+            out.update({"value": fst.num_suffixes / fdt, "sample_only": False, "sample_sweep": {"value": rate, "what": sweep_note},
+                        "sample": f"the WHOLE workload: {norm.size} bytes, {fst.num_suffixes} suffixes, {partitions} partitions, "
+                                  f"{bt} threads (the sweep's best on the prefix), {fdt:.1f} s wall (partition "
+                                  f"{fst.t_partition:.1f} s, sort {fst.t_sort:.1f} s)"})
+        except Exception as e:                   # the headline line must not depend on it
+            out["full_run_error"] = repr(e)[:200]
+    else:
+        print("bench.py: cpu_baseline is timed on a PREFIX of the workload only (sample_only: true): the whole-workload run "
+              "needs >= 200 GB of host memory and >= 32 cores, or was switched off", file=sys.stderr)
+    return out
 
 
-def e2e_create(text_cpu: np.ndarray, starts, flags: dict, partitions: int, s_total: int):
+def e2e_create(text_cpu: np.ndarray, starts, flags: dict, partitions: int, s_total: int, want_hash: bool = False):
     """`sufr create` end to end (t_create): the synthetic text written as a FASTA file, then
     the native CLI from FASTA parse to the closed .sufr file.  Reported next to `value`, never as `value`."""
     import shutil
@@ -139,6 +179,8 @@ def e2e_create(text_cpu: np.ndarray, starts, flags: dict, partitions: int, s_tot
         out_d = {"seconds": dt, "suffixes_per_s": s_total / dt, "fasta_bytes": fa.stat().st_size,
                  "sufr_bytes": out.stat().st_size, "phases": ph,
                  "what": "native `sufr create`: FASTA parse, H2D, build, D2H, .sufr written (process start-up included)"}
+        if want_hash:
+            out_d["sufr_sha256"] = file_sha256(out)
         if ph:
             # the four phases of the wall time: what the process reports since main() + what the caller's clock sees around it
             import re
@@ -171,7 +213,8 @@ def write_fasta(fa: Path, text_cpu: np.ndarray, starts):
                 f.write(seq[full:].tobytes() + b"\n")
 
 
-def e2e_create_sharded(text, starts, flags: dict, partitions: int, rank: int, world: int, local_rank: int, dev, backend):
+def e2e_create_sharded(text, starts, flags: dict, partitions: int, rank: int, world: int, local_rank: int, dev, backend,
+                       want_hash: bool = False):
     """`sufr create` with one process per GPU (N > 1): rank 0 writes the FASTA file, every rank parses it, builds its
     first-digit range on its own GPU and streams its SA / LCP slice into its range of the ONE output file
     (sufr_amd.shards.create_sharded: sufr_hip_shard_build, all_gather of 24 bytes per rank, sufr_write_frame,
@@ -209,8 +252,10 @@ def e2e_create_sharded(text, starts, flags: dict, partitions: int, rank: int, wo
         t = torch.tensor([dt, t1 - t0], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         s_total = sum(b[2] for b in bounds)
+        dist.barrier()               # every rank's slice is in the file
         return {"seconds": float(t[0]), "read_seconds": float(t[1]), "suffixes_per_s": s_total / float(t[0]),
                 "sufr_bytes": out.stat().st_size if rank == 0 else None, "shard_suffixes": [b[2] for b in bounds],
+                "sufr_sha256": file_sha256(out) if want_hash and rank == 0 else None,
                 "what": f"{world} ranks, one GPU each: FASTA parse (every rank), H2D, shard build, 24-byte all_gather, "
                         "D2H + every rank's slice written into the one .sufr file (contexts already up).  WRITE-BOUND: the "
                         "file is 8 bytes per suffix + the text and the page cache of one host takes ~11-15 GB/s whoever "
@@ -257,6 +302,43 @@ def search_rate(builder, norm, sa, dev, is_dna: bool, num_queries: int = 4_000_0
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a child process and return its exit code.  Called before any HIP / torch.cuda call (counting
+    devices does not initialise the GPU on this image); the child's ranks do the GPU work."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if not args.share_device and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this box shows {have} GPU(s).  One rank per GPU over RCCL needs {args.gpus}; to "
+              f"rehearse the N > 1 leg on one GPU use  --gpus {args.gpus} --backend gloo --share-device  (ranks share cuda:0, "
+              "host-side exchange)  or  SUFR_BENCH_FORCE_DIST=1 --gpus 1  (RCCL at world size 1, two shards per step)",
+              file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def file_sha256(path) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                return h.hexdigest()
+            h.update(b)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,25 +359,41 @@ def main():
                     help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing N>1 on one GPU)")
     ap.add_argument("--share-device", action="store_true",
                     help="smoke test: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true", default=bool(int(os.environ.get("SUFR_BENCH_FORCE_DIST", "0") or 0)),
+                    help="N = 1 only: initialise nccl (RCCL) at world size 1, build TWO first-digit shards per step and run the "
+                         "N > 1 exchange (all_gather on device tensors + sufr_hip_stitch_device_u32) on this one GPU")
+    ap.add_argument("--e2e-hash", action="store_true", help="add the sha256 of the .sufr file that e2e_create wrote to its record")
+    ap.add_argument("--full-cpu-baseline", choices=("auto", "on", "off"), default=os.environ.get("SUFR_BENCH_FULL_CPU", "auto"),
+                    help="time the CPU port on the WHOLE workload (auto: when the host has >= 200 GB and >= 32 cores)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: start the N ranks as a CHILD job (decided before anything touches the GPU; the
+        # parent only counts devices, waits and passes the child's output and exit code on -- it never execs)
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.force_dist and world != 1:
+        raise SystemExit("--force-dist / SUFR_BENCH_FORCE_DIST is the one-GPU rehearsal of the N > 1 step: use it with --gpus 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    elif args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    vshards = 2 if args.force_dist else 1          # first-digit shards this rank builds per step
 
     gen, default_bases, flags, partitions, label = WORKLOADS[args.workload]
     bases = args.bases or default_bases
@@ -317,42 +415,61 @@ def main():
 
     builder = sufr_amd.DeviceBuilder(local_rank)
     placement_ms = []
-    out_sa = out_lcp = None
+    out_sa = [None] * vshards
+    out_lcp = [None] * vshards
     stats_acc = []
     from sufr_amd import shards
     soft = flags.get("ignore_softmask", False)
     totals = {"s_total": 0}
+    num_shards = world * vshards
 
     def step():
-        sa, lcp = builder.sort(text, raw_text=True, shard_index=rank, num_shards=world, out_sa=out_sa,
-                               out_lcp=out_lcp, num_partitions=partitions, **flags)
-        s_local = builder.num_suffixes
-        if world > 1:
-            # the only exchange of the path: {first, last, count} per rank (24 bytes, assembled on the device and
-            # gathered into device memory), then the boundary-LCP stitch as a kernel on this rank's text
-            if args.backend == "nccl":
-                bounds = shards.gather_boundaries_device(sa, s_local, dist)
-                shards.stitch_device(builder.ctx, n, bounds, rank, lcp)
-                totals["bounds"] = bounds               # (read once, after the timed region)
-            else:
-                # gloo smoke test (CPU tensors): the host form of the same exchange
-                first = int(sa[0].item()) & 0xFFFFFFFF if s_local else 0
-                last = int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0
-                bl = shards.exchange_boundaries(first, last, s_local, "cpu", dist)
-                k = shards.stitched_first_lcp(
-                    bl, rank, lambda st, ln: sufr_amd.normalize(text[st:st + ln].cpu().numpy(), soft), n)
-                if k is not None:
-                    lcp[0] = k
-                totals["bounds"] = torch.tensor(bl, dtype=torch.int64)
-        else:
+        """One pass of the hot path on this rank: its first-digit shard(s) built, boundaries exchanged, first LCP stitched."""
+        outs, counts = [], []
+        for v in range(vshards):
+            sa, lcp = builder.sort(text, raw_text=True, shard_index=rank * vshards + v, num_shards=num_shards,
+                                   out_sa=out_sa[v], out_lcp=out_lcp[v], num_partitions=partitions, **flags)
+            outs.append((sa, lcp)); counts.append(builder.num_suffixes)
+            if vshards > 1:
+                stats_acc.append(builder.stats.as_dict())
+        s_local = counts[0]
+        sa, lcp = outs[0]
+        if num_shards == 1:
             totals["s_total"] = s_local
+        elif args.backend == "nccl" or args.force_dist:
+            # the only exchange of the path: {first, last, count} per shard (24 bytes, assembled on the device and
+            # gathered into device memory over RCCL), then the boundary-LCP stitch as a kernel on this rank's text
+            rows = [shards.gather_boundaries_device(o[0], c, dist, always_collective=True) for o, c in zip(outs, counts)]
+            bounds = torch.stack(rows, dim=1).reshape(num_shards, 3).contiguous()     # row = global shard index
+            for v in range(vshards):
+                shards.stitch_device(builder.ctx, n, bounds, rank * vshards + v, outs[v][1])
+            totals["bounds"] = bounds               # (read once, after the timed region)
+        else:
+            # gloo smoke test (CPU tensors): the host form of the same exchange
+            first = int(sa[0].item()) & 0xFFFFFFFF if s_local else 0
+            last = int(sa[s_local - 1].item()) & 0xFFFFFFFF if s_local else 0
+            bl = shards.exchange_boundaries(first, last, s_local, "cpu", dist)
+            k = shards.stitched_first_lcp(
+                bl, rank, lambda st, ln: sufr_amd.normalize(text[st:st + ln].cpu().numpy(), soft), n)
+            if k is not None:
+                lcp[0] = k
+            totals["bounds"] = torch.tensor(bl, dtype=torch.int64)
+        if vshards > 1:
+            totals["outs"] = outs
         return sa, lcp
 
     # size the output arrays once (first call allocates n entries; later calls reuse them)
     sa, lcp = step()
-    cap = int(builder.num_suffixes * 1.02) + 1024
-    out_sa = torch.empty(cap, dtype=torch.int32, device=dev)
-    out_lcp = torch.empty(cap, dtype=torch.int32, device=dev)
+    if vshards == 1:
+        cap = int(builder.num_suffixes * 1.02) + 1024
+        out_sa = [torch.empty(cap, dtype=torch.int32, device=dev)]
+        out_lcp = [torch.empty(cap, dtype=torch.int32, device=dev)]
+    else:
+        caps = [int(o[0].numel() * 1.02) + 1024 for o in totals["outs"]]
+        totals.pop("outs")
+        out_sa = [torch.empty(c, dtype=torch.int32, device=dev) for c in caps]
+        out_lcp = [torch.empty(c, dtype=torch.int32, device=dev) for c in caps]
+        stats_acc.clear()
     del sa, lcp
     torch.cuda.empty_cache()
     # Workspace placement: the device time of one build depends on where hipMalloc puts the work buffers
@@ -391,21 +508,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    stats_acc.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sa, lcp = step()
-        stats_acc.append(builder.stats.as_dict())
+        if vshards == 1:
+            stats_acc.append(builder.stats.as_dict())
     barrier()
     dt = time.perf_counter() - t0
     dt = allmax(dt)
 
-    if world > 1:
+    if num_shards > 1:
         totals["s_total"] = int(totals["bounds"][:, 2].sum().item())      # one read-back, outside the timed region
     s_total = totals["s_total"]
     verified = None
     search = None
-    if world == 1 and not args.no_verify:
+    forced = None
+    if args.force_dist:
+        # outside the timed region: the two stitched shards of the last timed step, concatenated, against ONE unsharded
+        # build of the same text on the same context -- whole arrays, every element
+        outs = totals.pop("outs")
+        cat_sa = torch.cat([o[0] for o in outs]); cat_lcp = torch.cat([o[1] for o in outs])
+        one_sa, one_lcp = builder.sort(text, raw_text=True, num_partitions=partitions, **flags)
+        forced = {"backend": "nccl (RCCL), world size 1", "virtual_shards": vshards,
+                  "shard_suffixes": [int(o[0].numel()) for o in outs],
+                  "equal_to_single_build": bool(torch.equal(cat_sa, one_sa) and torch.equal(cat_lcp, one_lcp)),
+                  "stitched_first_lcp": int(outs[1][1][0].item()) if outs[1][1].numel() else None,
+                  "what": "every timed step = 2 shard builds + all_gather_into_tensor of the {first, last, count} triples on "
+                          "device tensors (RCCL) + sufr_hip_stitch_device_u32 on the context's stream; ms_per_step is the "
+                          "time of BOTH shards on one GPU, not an N = 2 figure"}
+        assert forced["equal_to_single_build"], "forced-dist: stitched shards differ from the single build"
+        del cat_sa, cat_lcp, one_sa, one_lcp
+    if num_shards == 1 and not args.no_verify:
         # outside the timed region: the arrays of the last timed step against the text (sufr_amd/verify.py)
         sys.path.insert(0, str(ROOT / "tests"))
         import gpu_verify as verify          # the GPU-side property checker: test infrastructure, like oracle/
@@ -422,14 +557,22 @@ def main():
             search = search_rate(builder, norm, sa, dev, bool(flags.get("is_dna", False)))
         del norm
 
+    per_rank = None
+    if world > 1:
+        keys = ["ms_total", "ms_normalize", "ms_hist_text", "ms_partition", "ms_passes", "ms_finish", "ms_deep"]
+        mine = {k: round(float(np.mean([st_[k] for st_ in stats_acc])), 3) for k in keys}
+        mine["num_suffixes"] = int(stats_acc[-1]["num_suffixes"])
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     e2e_multi = None
     if world > 1 and not args.no_e2e:
         builder.close()              # every rank's bench context makes room for its create context
-        e2e_multi = e2e_create_sharded(text, starts, flags, partitions, rank, world, local_rank, dev, args.backend)
+        e2e_multi = e2e_create_sharded(text, starts, flags, partitions, rank, world, local_rank, dev, args.backend,
+                                       want_hash=args.e2e_hash)
 
     if rank == 0:
         keys = ["ms_total", "ms_normalize", "ms_hist_text", "ms_partition", "ms_passes", "ms_finish", "ms_deep"]
-        avg = {k: float(np.mean([s[k] for s in stats_acc])) for k in keys}
+        avg = {k: float(np.mean([s[k] for s in stats_acc])) for k in keys}      # (forced-dist: per SHARD build)
         st = stats_acc[-1]
         # radix-partition kernel (k_scatter_text): algorithmic bytes per launch = n (text) + 4 s (indices),
         # SURVEY.md 8(d) / BASELINE.md section 4; s = suffixes this rank keeps
@@ -437,7 +580,7 @@ def main():
         achieved = alg_bytes / (avg["ms_partition"] * 1e-3) / 1e9 if avg["ms_partition"] > 0 else 0.0
         # HBM bytes of that launch from the PMC counters: read from the committed summary of a profiled run of this same
         # command (the counters need rocprofv3 passes of their own), and labelled with the file they come from
-        traffic, traffic_src = pmc_traffic_bytes(args.workload) if world == 1 and not args.bases else (None, None)
+        traffic, traffic_src = pmc_traffic_bytes(args.workload) if num_shards == 1 and not args.bases else (None, None)
         out = {
             "metric": "suffixes sorted/sec (SA+LCP)",
             "value": s_total * args.steps / dt,
@@ -447,11 +590,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "value_best": (s_total / (min(placement_ms) * 1e-3)) if placement_ms and world == 1 else None,
+            "value_best": (s_total / (min(placement_ms) * 1e-3)) if placement_ms and num_shards == 1 else None,
             "dtype": "u8 text / u32 indices / u64 packed keys",
             "data": data,
             "config": {"workload": label, "text_len": n, "num_suffixes": s_total,
-                       "parallelism": f"prefix-bucket shards x{world}", "bits_per_char": st["bits_per_char"],
+                       "parallelism": f"prefix-bucket shards x{num_shards}" + (" (two per step on ONE GPU: forced-dist rehearsal)" if args.force_dist else ""), "bits_per_char": st["bits_per_char"],
                        "radix_passes": st["num_passes"], "digit_bits": st["digit_bits"],
                        "levels": st["num_levels"], "deep_records": st["deep_records"],
                        "placement_trials": max(1, args.placement_trials), "placement_ms": placement_ms},
@@ -466,18 +609,38 @@ def main():
         }
         if search is not None:
             out["search"] = search
+        if forced is not None:
+            out["forced_dist"] = forced
+        if world > 1:
+            # what a rank cannot shed: every rank streams the WHOLE text through the text pass
+            # (ms_normalize + ms_hist_text) and through the scan side of the partition kernel; only the rest shrinks with N
+            fixed = [round(r["ms_normalize"] + r["ms_hist_text"], 3) for r in per_rank]
+            out["per_rank"] = {"device_ms": per_rank, "text_pass_ms": fixed,
+                               "note": "strong scaling with a per-rank fixed cost: every rank reads the whole text in the text "
+                                       "pass (text_pass_ms) and in the scan of the partition kernel (~2.5 ms of ms_partition at "
+                                       "3.1 Gb); sorting work (ms_passes, ms_deep, the rest of ms_partition) is ~1/N.  One-GPU "
+                                       "shard probe (profiles/r04_shard_probe.txt): 53.7 / 31.2 / 20.4 / 14.9 ms per rank at "
+                                       "N = 1 / 2 / 4 / 8 => at most 86 / 66 / 45 % efficiency before any communication"}
+            if args.share_device:
+                out["per_rank"]["share_device"] = ("all ranks ran on cuda:0 (smoke test of the N > 1 leg on a one-GPU box): "
+                                                   "value is NOT an N-GPU figure")
         if world == 1 and not args.no_cpu_baseline:
             sample_bases = min(bases, 400_000_000)
-            out["cpu_baseline"] = cpu_baseline(text[:sample_bases].cpu().numpy(), flags, partitions)
+            full = None
+            big_host = host_memory_gb() >= 200 and (os.cpu_count() or 1) >= 32
+            if args.full_cpu_baseline == "on" or (args.full_cpu_baseline == "auto" and big_host and n > sample_bases + 1):
+                full = lambda: text.cpu().numpy()       # noqa: E731 -- the oracle needs ~24 bytes per base of host memory
+            out["cpu_baseline"] = cpu_baseline(text[:sample_bases].cpu().numpy(), flags, partitions, full_text=full)
         if world == 1 and not args.no_e2e:
             builder.close()          # the CLI is its own process with its own context: free this one's HBM first
-            out["e2e_create"] = e2e_create(text.cpu().numpy(), starts, flags, partitions, s_total)
+            out["e2e_create"] = e2e_create(text.cpu().numpy(), starts, flags, partitions, s_total, want_hash=args.e2e_hash)
         if e2e_multi is not None:
             out["e2e_create"] = e2e_multi
         print(json.dumps(out), flush=True)
     builder.close()
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -257,7 +257,9 @@ int sufr_write_frame(const char *outfile, const sufr_sequence_data *seq, const s
                      uint64_t total_suffixes, char *err, size_t errlen);
 /* streams the resident shard (num_suffixes entries) to its place, suffix_offset entries into the SA / LCP sections
  * of the existing `outfile`; has_prev: LCP[0] of the shard is first set to the boundary LCP with prev_last_suffix;
- * write_text: this rank also writes the normalised text (rank 0) */
+ * write_text: this rank also writes the normalised text (rank 0).  CONSUMES the resident build: when it returns, the
+ * context's SA / LCP / work arrays are released (and, with write_text == 0, its copy of the text); a second call without a
+ * new sufr_hip_shard_build returns SUFR_HIP_E_INVALID. */
 int sufr_hip_shard_write(sufr_hip_ctx *ctx, const sufr_sequence_data *seq, const sufr_create_args *args,
                          const char *outfile, uint64_t num_suffixes, uint64_t total_suffixes,
                          uint64_t suffix_offset, int has_prev, uint64_t prev_last_suffix, int write_text);

@@ -763,10 +763,19 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
     // The text section (the normalised text, sufr_builder.rs:871) does not wait for the build: its place in the file is
     // known from the header alone, and the text map 144-160 is a byte table -- host threads map 32 MB pieces and write them
     // while the GPUs partition and sort (3.1 of the 15.1 GB of a human-sized file, off the D2H + write phase).
-    // (everything is written under "<output>.partial" and renamed at the end: a failed build leaves an existing file alone)
-    const std::string partial = outfile + ".partial";
-    int tfd = ::open(partial.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    // Written under "<output>.partial" and renamed at the end -- a failed build leaves an existing file alone -- but ONLY when
+    // the output does not exist yet or is a plain file with one name: a rename would replace a symlink instead of writing
+    // through it, drop the other names of a hard-linked file, and put a 15 GB regular file where /dev/null or a FIFO was
+    // (`sufr create -o /dev/null` is a common way to time a build).  Anything else is opened in place, as the reference's
+    // File::create does (sufr_builder.rs:819), and never unlinked.
+    struct stat ost;
+    const int lrc = lstat(outfile.c_str(), &ost);
+    const bool in_place = lrc == 0 ? !(S_ISREG(ost.st_mode) && ost.st_nlink == 1) : errno != ENOENT;
+    const std::string partial = in_place ? outfile : outfile + ".partial";
+    auto discard = [&]() { if (!in_place) (void)unlink(partial.c_str()); };
+    int tfd = ::open(partial.c_str(), O_WRONLY | O_CREAT | O_TRUNC, lrc == 0 && !in_place ? (ost.st_mode & 07777) : 0644);
     if (tfd < 0) { sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str()); return SUFR_HIP_E_IO; }
+    if (lrc == 0 && !in_place) (void)fchmod(tfd, ost.st_mode & 07777);     // (the umask does not get a say over an existing file's mode)
     std::atomic<int> text_failed{0};
     std::vector<std::thread> text_writers;
     {
@@ -805,7 +814,7 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
     }
     for (int r = 0; r < n_ctx; r++)
         if (rcs[r]) {
-            (void)finish_text(); (void)unlink(partial.c_str());
+            (void)finish_text(); discard();
             if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r]));
             return rcs[r];
         }
@@ -819,7 +828,7 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
         if (!pwrite_all(tfd, L.head.data(), L.head.size(), 0) || !pwrite_all(tfd, L.tail.data(), L.tail.size(), L.tail_pos)) rc = SUFR_HIP_E_IO;
     }
     if (rc != 0) {
-        (void)finish_text(); (void)unlink(partial.c_str());
+        (void)finish_text(); discard();
         sufr_hip_set_error_(ctx0, (outfile + ": write failed").c_str());
         return rc;
     }
@@ -837,19 +846,19 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
         for (auto& x : th) x.join();
     }
     if (!finish_text()) {
-        (void)unlink(partial.c_str());
+        discard();
         sufr_hip_set_error_(ctx0, (outfile + ": write failed").c_str());
         return SUFR_HIP_E_IO;
     }
     for (int r = 0; r < n_ctx; r++)
         if (rcs[r]) {
-            (void)unlink(partial.c_str());               // no valid header over missing sections left behind
+            discard();                                   // no valid header over missing sections left behind
             if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r]));
             return rcs[r];
         }
-    if (rename(partial.c_str(), outfile.c_str()) != 0) {
+    if (!in_place && rename(partial.c_str(), outfile.c_str()) != 0) {
         sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str());
-        (void)unlink(partial.c_str());
+        discard();
         return SUFR_HIP_E_IO;
     }
     if (stats) {

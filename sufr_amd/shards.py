@@ -26,10 +26,12 @@ def exchange_boundaries(first: int, last: int, count: int, device, dist=None) ->
     return [tuple(int(v) for v in t.tolist()) for t in out]
 
 
-def gather_boundaries_device(sa, count: int, dist=None):
+def gather_boundaries_device(sa, count: int, dist=None, always_collective: bool = False):
     """The same exchange without a host round trip: the triple is assembled on the device from the shard's own
     suffix array (sa: the int32 / int64 tensor sufr_hip_sort_device_* filled, `count` entries valid) and gathered into
-    a [world, 3] int64 tensor that stays in device memory (backend nccl = RCCL; gloo accepts CPU tensors)."""
+    a [world, 3] int64 tensor that stays in device memory (backend nccl = RCCL; gloo accepts CPU tensors).
+    always_collective: run the all_gather even in a process group of ONE rank (bench.py's forced-dist rehearsal: the
+    RCCL call and its stream ordering against the stitch kernel execute on a one-GPU box)."""
     dev = sa.device
     if count:
         ends = torch.stack([sa[0], sa[count - 1]]).to(torch.int64) & 0xFFFFFFFF if sa.dtype == torch.int32 \
@@ -37,7 +39,7 @@ def gather_boundaries_device(sa, count: int, dist=None):
     else:
         ends = torch.zeros(2, dtype=torch.int64, device=dev)
     mine = torch.cat([ends, torch.tensor([count], dtype=torch.int64, device=dev)])
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return mine.view(1, 3)
     out = torch.empty(dist.get_world_size(), 3, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(out.view(-1), mine)

@@ -91,7 +91,7 @@ class SufrFile:
         if rc != 0:
             raise SufrHipError(rc, err.value.decode())
         import threading
-        self._view_lock = threading.Lock()
+        self._view_lock = threading.RLock()       # re-entrant: a GC pass inside _view() can finalise a dead view of this file on the same thread
         self._live_views = 0
         self._close_pending = False
         self._h = h
