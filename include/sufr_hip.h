@@ -108,9 +108,17 @@ int  sufr_hip_synchronize(sufr_hip_ctx *ctx);
  * margin: comparison context after them; 0, 0 selects the defaults (as few windows as fit, 2^26).  A non-zero window
  * also sends shorter texts of more than `window` bytes down the same path (memory-bound callers; the tests).
  * max_query_len / seed_mask builds take the same windows (built with the option, merged under its order).  A repeat
- * that crosses the end of a window and is longer than the widest margin 32 bits allow (~2^31 symbols) is the one
- * input the windowed build returns SUFR_HIP_E_UNSUPPORTED for. */
+ * that crosses the end of a window and is longer than the margin makes the window re-build with the widest margin
+ * (what 32 bits leave beside the window, ~2^31 symbols); one longer than that too is ordered by comparisons over the
+ * whole text with 64-bit positions (round 5: the suffixes the window only saw a prefix of leave its arrays and are
+ * merged back as a list of their own -- correct for any repeat, slow for long ones: every comparison walks the
+ * repeat).  SUFR_HIP_E_UNSUPPORTED is left for more than 2^22 such suffixes in one window. */
 int  sufr_hip_set_window(sufr_hip_ctx *ctx, uint64_t window, uint64_t margin);
+/* widest_margin: cap of the margin of that re-build (0: what 32 bits allow).  A re-build with a 2^31-symbol margin is a
+ * second full-size window: callers short of memory -- and the tests of the whole-text repair -- bound it. */
+int  sufr_hip_set_window_retry(sufr_hip_ctx *ctx, uint64_t widest_margin);
+/* suffixes of the context's last windowed build that were ordered by whole-text comparison (0: no window needed it) */
+uint64_t sufr_hip_window_repairs(const sufr_hip_ctx *ctx);
 
 /* ---- text normalisation: sufr_builder.rs:144-160 (host helper; the GPU build can also do it) --- */
 int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_softmask);

@@ -33,6 +33,58 @@ k_scatter(Rec* __restrict__ out, const uint32_t* __restrict__ bucket_base, uint3
     }
 }
 
+// XCD-local write combining (the micro-benchmark).  Per (group = XCD, bin) a staging block of
+// BLK records in global memory that is only ever touched by that XCD (so it lives in that XCD's L2: 2 700 x 1 152 B = 3.1 MB of
+// 4 MB); a tile APPENDS its r-record run to the block (returning atomic on the staging cursor, wrap-around inside the block) and
+// the workgroup whose append crosses the end of the block FLUSHES it: reads the BLK records back (L2 hits, if the block stayed)
+// and writes them as ONE run of BLK records to the bin's place in the output.  This is the TRAFFIC of the scheme and nothing
+// else -- no completion counters, nobody waits for the other appenders of a block, the flushed bytes may be stale --: a LOWER
+// bound on what a correct implementation would take.  nt: the final stores carry the non-temporal hint (they should not push
+// the staging blocks out of the L2).
+template <bool NT_STORE>
+__global__ void __launch_bounds__(1024)
+k_combine(Rec* __restrict__ out, Rec* __restrict__ stage, const uint32_t* __restrict__ bucket_base, uint32_t* __restrict__ cursor,
+          uint32_t* __restrict__ scur, uint32_t NB, uint32_t r, uint32_t BLK, uint32_t tiles)
+{
+    extern __shared__ uint32_t s_base[];           // NB staging offsets, then the flush list (bin, final base) x NB, then its length
+    uint32_t* s_flush = s_base + NB;
+    uint32_t* s_nf = s_flush + 2 * NB;
+    const uint32_t g = blockIdx.x & 7u;
+    Rec* st = stage + (size_t)g * NB * BLK;
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) *s_nf = 0;
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < NB; d += 1024) {
+            const uint32_t p = atomicAdd(&scur[(size_t)g * NB + d], r);
+            s_base[d] = p % BLK;
+            if (p / BLK != (p + r) / BLK) {          // this append fills the block: flush it to the bin's next BLK slots
+                const uint32_t k = atomicAdd(s_nf, 1u);
+                s_flush[2 * k] = d;
+                s_flush[2 * k + 1] = bucket_base[d] + atomicAdd(&cursor[(size_t)g * NB + d], BLK);
+            }
+        }
+        __syncthreads();
+        const uint32_t total = NB * r;
+        for (uint32_t j = threadIdx.x; j < total; j += 1024) {
+            const uint32_t d = j / r, o = j - d * r;
+            uint32_t q = s_base[d] + o;
+            if (q >= BLK) q -= BLK;
+            st[(size_t)d * BLK + q] = Rec{j, t, d};
+        }
+        __syncthreads();                             // (the appends of THIS workgroup are visible to it; others' are not waited for)
+        const uint32_t nf = *s_nf, ftotal = nf * BLK;
+        for (uint32_t j = threadIdx.x; j < ftotal; j += 1024) {
+            const uint32_t k = j / BLK, o = j - k * BLK;
+            const Rec v = st[(size_t)s_flush[2 * k] * BLK + o];
+            Rec* dst = out + (size_t)s_flush[2 * k + 1] + o;
+            if (NT_STORE) {
+                __builtin_nontemporal_store(v.a, &dst->a); __builtin_nontemporal_store(v.b, &dst->b); __builtin_nontemporal_store(v.c, &dst->c);
+            } else *dst = v;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(1024)
 k_stream(Rec* __restrict__ out, uint64_t records)
 {
@@ -81,6 +133,37 @@ int main(int argc, char** argv)
         const double runs = (double)tiles * NB, lines = written * 12.0 / 64.0 + runs * (1.0 - 12.0 / 64.0) * 0.0;   // (lower bound: payload / 64)
         printf("bins %5u  run %4u rec (%5u B): %7.2f ms  %6.0f GB/s  >= %5.1f G lines/s  (%.3g runs)\n", NB, r, r * 12, best,
                written * 12.0 / best / 1e6, lines / best / 1e6, runs);
+    }
+    // ---- XCD-local write combining: r = 12 records per append (the stand-in's pattern), blocks of BLK records ----
+    {
+        const uint32_t r = 12;
+        const uint32_t tiles = (uint32_t)(records / ((uint64_t)NB * r));
+        std::vector<uint32_t> hb(NB);
+        for (uint32_t d = 0; d < NB; d++) hb[d] = (uint32_t)((uint64_t)d * tiles * r);
+        CK(hipMemcpy(base, hb.data(), (size_t)NB * 4, hipMemcpyHostToDevice));
+        uint32_t* scur; CK(hipMalloc(&scur, (size_t)8 * NB * 4));
+        for (uint32_t BLK : {48u, 64u, 96u, 128u, 192u}) {
+            Rec* stage; CK(hipMalloc(&stage, (size_t)8 * NB * BLK * sizeof(Rec)));
+            for (int nt = 0; nt < 2; nt++) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; rep++) {
+                    std::vector<uint32_t> hc((size_t)8 * NB, 0u);
+                    const uint32_t per_group = (tiles + 7) / 8 * r;
+                    for (uint32_t g = 0; g < 8; g++) for (uint32_t d = 0; d < NB; d++) hc[(size_t)g * NB + d] = g * per_group;
+                    CK(hipMemcpy(cursor, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+                    CK(hipMemset(scur, 0, (size_t)8 * NB * 4));
+                    CK(hipEventRecord(e0));
+                    const size_t lds = (size_t)NB * 12 + 16;
+                    if (nt) hipLaunchKernelGGL(k_combine<true>, dim3(grid), dim3(1024), lds, 0, out, stage, base, cursor, scur, NB, r, BLK, tiles);
+                    else hipLaunchKernelGGL(k_combine<false>, dim3(grid), dim3(1024), lds, 0, out, stage, base, cursor, scur, NB, r, BLK, tiles);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+                }
+                printf("combine bins %5u  append %u rec, block %4u rec (%5u B, staging %.1f MB per XCD)%s: %7.2f ms\n", NB, r, BLK, BLK * 12,
+                       NB * BLK * 12.0 / 1e6, nt ? " nt stores" : "          ", best);
+            }
+            CK(hipFree(stage));
+        }
     }
     return 0;
 }

@@ -42,6 +42,8 @@ const char* sufr_hip_last_error(const sufr_hip_ctx* ctx) { return ctx ? ctx->err
 int sufr_hip_set_stream(sufr_hip_ctx* ctx, void*) { return no_device(ctx); }
 int sufr_hip_synchronize(sufr_hip_ctx* ctx) { return no_device(ctx); }
 int sufr_hip_set_window(sufr_hip_ctx* ctx, uint64_t, uint64_t) { return no_device(ctx); }
+int sufr_hip_set_window_retry(sufr_hip_ctx* ctx, uint64_t) { return no_device(ctx); }
+uint64_t sufr_hip_window_repairs(const sufr_hip_ctx*) { return 0; }
 int sufr_hip_sort_device_u32(sufr_hip_ctx* ctx, const void*, uint64_t, uint32_t, uint64_t, const char*, uint64_t, uint64_t,
                              uint32_t, uint32_t, void*, void*, uint64_t, uint64_t*, sufr_hip_stats*) { return no_device(ctx); }
 int sufr_hip_sort_device_u64(sufr_hip_ctx* ctx, const void*, uint64_t, uint32_t, uint64_t, const char*, uint64_t, uint64_t,

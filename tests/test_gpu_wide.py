@@ -272,3 +272,73 @@ def test_cli_creates_masked_and_truncated_files_in_windows(tmp_path):
     r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-d", "-o", str(tmp_path / "y.sufr"), "--window", "4096", "-m", "0"],
                        capture_output=True, text=True)                                   # Some(0): a plain build
     assert r.returncode == 0, r.stderr
+
+# ---- round 5: a repeat longer than the WIDEST margin -------------------------------------------------
+def build_capped(x, window, margin, retry, index_width, **flags):
+    """like build(), with the re-build margin capped (sufr_hip_set_window_retry): repeats longer than `retry` take the
+    whole-text repair (sufr_wide.inc, repair_window); returns the number of suffixes it ordered too"""
+    db = sufr_amd.DeviceBuilder(0)
+    db.ctx.set_window(window, margin)
+    db.ctx.set_window_retry(retry)
+    sa, lcp = db.sort(x, index_width=index_width, **flags)
+    sa, lcp = sa.cpu().numpy(), lcp.cpu().numpy()
+    repaired = db.ctx.window_repairs
+    db.close()
+    if index_width == 4:
+        sa, lcp = sa.view(np.uint32), lcp.view(np.uint32)
+    return sa.astype(np.uint64), lcp.astype(np.uint64), repaired
+
+
+@pytest.mark.parametrize("index_width", [4, 8])
+@pytest.mark.parametrize("window,margin,retry", [(5000, 300, 100), (4096, 64, 64), (8000, 100, 500), (20000, 16, 16)])
+@pytest.mark.parametrize("flags", [dict(is_dna=True), dict(is_dna=True, allow_ambiguity=True), dict()])
+def test_repeat_longer_than_the_widest_margin_is_ordered_over_the_whole_text(oracle, window, margin, retry, index_width, flags):
+    """40 copies of a 900-symbol repeat cross every window boundary and the re-build margin is capped BELOW the repeat: rounds
+    2-4 returned SUFR_HIP_E_UNSUPPORTED here ("true 64-bit records are not built yet").  Now the suffixes the window saw only
+    a prefix of are ordered by whole-text comparison with 64-bit positions and merged back: the oracle's arrays, bit for bit."""
+    t = repeat_text(60_000, 1, 900, 40)
+    want_sa, want_lcp, _ = oracle.build(t, **flags)
+    sa, lcp, repaired = build_capped(torch.from_numpy(t).cuda(), window, margin, retry, index_width, **flags)
+    assert repaired > 0 or retry > 100, "the cap did not force the repair path"     # (a 500-symbol cap: only if a copy lies just so)
+    assert np.array_equal(sa, want_sa.astype(np.uint64))
+    assert np.array_equal(lcp, want_lcp.astype(np.uint64))
+
+
+def test_long_exact_duplicates_across_capped_windows(oracle):
+    """exact copies of a 3 000-symbol segment 3 500 symbols apart (both inside one window + margin, the second one cut by its
+    end) and a 3 000-symbol homopolymer that ends behind a capped margin, windows of ~6 250 with re-build margins of at most
+    400: thousands of suffixes tie through the end of their window, with common prefixes of thousands of symbols"""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = acgt[rng.integers(0, 4, 50_000)].copy()
+    seg = t[1_000:4_000].copy()
+    for at in (4_500, 30_100):
+        t[at:at + seg.size] = seg
+    t[41_000:44_000] = ord("T")
+    t[-1] = ord("$")
+    want_sa, want_lcp, _ = oracle.build(t, is_dna=True)
+    for index_width in (4, 8):
+        sa, lcp, repaired = build_capped(torch.from_numpy(t).cuda(), 7_000, 200, 400, index_width, is_dna=True)
+        assert repaired > 1_000
+        assert np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
+
+
+@pytest.mark.parametrize("L", [50, 700, 2_000])
+def test_max_query_len_above_the_capped_margin_equals_the_one_window_build(L):
+    """-m L with L above the capped re-build margin: the suffixes with fewer than L symbols inside their window are ordered
+    over the whole text under the capped order (first L symbols, then descending position)"""
+    t = repeat_text(60_000, 5, 900, 40)
+    x = torch.from_numpy(t).cuda()
+    db = sufr_amd.DeviceBuilder(0)
+    one_sa, one_lcp = (a.cpu().numpy().view(np.uint32).astype(np.uint64) for a in db.sort(x, is_dna=True, max_query_len=L))
+    db.close()
+    sa, lcp, repaired = build_capped(x, 6_000, 40, 40, 4, is_dna=True, max_query_len=L)
+    assert repaired > 0
+    assert np.array_equal(sa, one_sa) and np.array_equal(lcp, one_lcp)
+
+
+def test_repairs_are_zero_when_the_margin_suffices(oracle):
+    t = repeat_text(60_000, 1, 900, 40)
+    sa, lcp, repaired = build_capped(torch.from_numpy(t).cuda(), 5000, 3000, 0, 4, is_dna=True)
+    want_sa, want_lcp, _ = oracle.build(t, is_dna=True)
+    assert repaired == 0 and np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
