@@ -151,7 +151,12 @@ int sufr_hip_sort_device_u32(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, 
                              uint64_t *num_suffixes_out, sufr_hip_stats *stats);
 /* u64-index twin (SufrBuilder<u64>; suffix_array.rs:461 selects it when n >= u32::MAX).  Texts below
  * 2^32 - 2^24 bytes are built with 32-bit indices on the device and widened; longer texts take the windowed build
- * (sufr_hip_set_window above; single-shard: num_shards > 1 returns SUFR_HIP_E_UNSUPPORTED for them). */
+ * (sufr_hip_set_window above).  Round 5: a windowed build shards too (both entry points): the shards are ranges of the
+ * suffixes' first 8 bytes, chosen from a fixed sample of the text -- identical on every rank, no communication --, every
+ * window keeps the suffixes of the shard's range and the rank merge runs per shard; the shards concatenate to the single
+ * build and the first LCP of a shard is stitched by sufr_hip_stitch_device_u32 / _u64.  (Every rank still builds every
+ * window in full: what shrinks with the number of shards is the filter, the merge and the output.)  Seed-mask builds and
+ * caps below 8 symbols are not sharded in windows (SUFR_HIP_E_UNSUPPORTED). */
 int sufr_hip_sort_device_u64(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, uint32_t flags,
                              uint64_t max_query_len, const char *seed_mask,
                              uint64_t num_partitions, uint64_t random_seed,
@@ -166,6 +171,9 @@ int sufr_hip_sort_device_u64(sufr_hip_ctx *ctx, const void *d_text, uint64_t n, 
  * suffix with the last suffix of the nearest non-empty shard before it, on the device text of the context's last
  * build; the pair never visits the host.  Shard 0 and empty shards are left as they are. */
 int sufr_hip_stitch_device_u32(sufr_hip_ctx *ctx, uint64_t n, const uint64_t *d_bounds, uint32_t shard_index,
+                               uint32_t num_shards, void *d_lcp);
+/* the same for a 64-bit LCP array (the shards of sufr_hip_sort_device_u64) */
+int sufr_hip_stitch_device_u64(sufr_hip_ctx *ctx, uint64_t n, const uint64_t *d_bounds, uint32_t shard_index,
                                uint32_t num_shards, void *d_lcp);
 
 /* Host-buffer variants: H2D copy of the text, build, D2H copy of SA and LCP.

@@ -80,7 +80,7 @@ FLAG_SA_U64 = 0x200               # sufr_hip_index_wrap only: 64-bit suffix arra
 EXPORTS = [
     "sufr_hip_abi_version", "sufr_hip_device_count", "sufr_hip_create", "sufr_hip_destroy",
     "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_synchronize", "sufr_hip_set_window", "sufr_hip_set_window_retry", "sufr_hip_window_repairs", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
-    "sufr_hip_sort_device_u64", "sufr_hip_stitch_device_u32", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
+    "sufr_hip_sort_device_u64", "sufr_hip_stitch_device_u32", "sufr_hip_stitch_device_u64", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
     "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file", "sufr_hip_create_from_sequence",
     "sufr_hip_shard_build", "sufr_write_frame", "sufr_hip_shard_write", "sufr_hip_create_from_sequence_multi",
     "sufr_hip_create_file_multi",
@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
     L.sufr_hip_build_u64.argtypes = host_sig; L.sufr_hip_build_u64.restype = C.c_int
     L.sufr_hip_lcp_pair.argtypes = [vp, u64, u64, u64]; L.sufr_hip_lcp_pair.restype = u64
     L.sufr_hip_stitch_device_u32.argtypes = [vp, u64, vp, u32, u32, vp]; L.sufr_hip_stitch_device_u32.restype = C.c_int
+    L.sufr_hip_stitch_device_u64.argtypes = [vp, u64, vp, u32, u32, vp]; L.sufr_hip_stitch_device_u64.restype = C.c_int
     L.sufr_read_sequence_file.argtypes = [cp, C.c_uint8, C.POINTER(SequenceData), cp, C.c_size_t]
     L.sufr_read_sequence_file.restype = C.c_int
     L.sufr_sequence_data_free.argtypes = [C.POINTER(SequenceData)]; L.sufr_sequence_data_free.restype = None

@@ -49,6 +49,7 @@ int sufr_hip_sort_device_u32(sufr_hip_ctx* ctx, const void*, uint64_t, uint32_t,
 int sufr_hip_sort_device_u64(sufr_hip_ctx* ctx, const void*, uint64_t, uint32_t, uint64_t, const char*, uint64_t, uint64_t,
                              uint32_t, uint32_t, void*, void*, uint64_t, uint64_t*, sufr_hip_stats*) { return no_device(ctx); }
 int sufr_hip_stitch_device_u32(sufr_hip_ctx* ctx, uint64_t, const uint64_t*, uint32_t, uint32_t, void*) { return no_device(ctx); }
+int sufr_hip_stitch_device_u64(sufr_hip_ctx* ctx, uint64_t, const uint64_t*, uint32_t, uint32_t, void*) { return no_device(ctx); }
 int sufr_hip_build_u32(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, uint64_t, const char*, uint64_t, uint64_t, uint8_t*,
                        uint32_t*, uint32_t*, uint64_t, uint64_t*, sufr_hip_stats*) { return no_device(ctx); }
 int sufr_hip_build_u64(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, uint64_t, const char*, uint64_t, uint64_t, uint8_t*,

@@ -2772,9 +2772,10 @@ k_lcp_pair(const uint8_t* __restrict__ text, uint64_t n, uint64_t a, uint64_t b,
 // {first suffix, last suffix, count} of every shard (the 24 bytes per rank of the all_gather, still in HBM);
 // LCP[0] of shard `rank` := find_lcp(last suffix of the nearest non-empty shard before it, SA[0], text_len, 0).
 // No host round trip: the pair is read from `bounds` here.
+template <typename LT>                                     // uint32_t; uint64_t for the shards of a windowed build
 __global__ void __launch_bounds__(256)
 k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long long* __restrict__ bounds, uint32_t rank,
-             uint32_t* __restrict__ lcp, StitchOrder so)
+             LT* __restrict__ lcp, StitchOrder so)
 {
     __shared__ uint32_t s_first;
     if (bounds[(size_t)rank * 3 + 2] == 0ull) return;
@@ -2782,7 +2783,7 @@ k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long l
     while (prev >= 0 && bounds[(size_t)prev * 3 + 2] == 0ull) prev--;
     if (prev < 0) return;                                  // the globally first suffix: LCP 0, as the build left it
     const uint64_t a = bounds[(size_t)prev * 3 + 1], b = bounds[(size_t)rank * 3];
-    if (so.offs) { if (threadIdx.x == 0) lcp[0] = (uint32_t)masked_pair_lcp(text, n, a, b, so); return; }
+    if (so.offs) { if (threadIdx.x == 0) lcp[0] = (LT)masked_pair_lcp(text, n, a, b, so); return; }
     const uint64_t lim = n - (a > b ? a : b);          // characters both suffixes have
     for (uint64_t k = 0;; k += 4096) {
         if (threadIdx.x == 0) s_first = 0xffffffffu;
@@ -2798,7 +2799,7 @@ k_lcp_stitch(const uint8_t* __restrict__ text, uint64_t n, const unsigned long l
         const uint32_t f = s_first;
         __syncthreads();
         if (f != 0xffffffffu || (so.cap && k + 4096 >= so.cap)) {
-            if (threadIdx.x == 0) { uint64_t v = f != 0xffffffffu ? k + f : so.cap; if (so.cap && v > so.cap) v = so.cap; lcp[0] = (uint32_t)v; }
+            if (threadIdx.x == 0) { uint64_t v = f != 0xffffffffu ? k + f : so.cap; if (so.cap && v > so.cap) v = so.cap; lcp[0] = (LT)v; }
             return;
         }
     }

@@ -55,7 +55,8 @@ def stitch_device(ctx, text_len: int, bounds, rank: int, lcp) -> None:
     if world == 1 or rank == 0:
         return
     torch.cuda.current_stream(bounds.device).synchronize()
-    ctx.check(_lib.lib().sufr_hip_stitch_device_u32(ctx.handle, text_len, bounds.data_ptr(), rank, world, lcp.data_ptr()))
+    fn = _lib.lib().sufr_hip_stitch_device_u64 if lcp.dtype == torch.int64 else _lib.lib().sufr_hip_stitch_device_u32
+    ctx.check(fn(ctx.handle, text_len, bounds.data_ptr(), rank, world, lcp.data_ptr()))
 
 
 def output_offset(boundaries: List[Boundary], rank: int) -> int:

@@ -224,9 +224,31 @@ def test_text_beyond_32_bits():
     res = verify.check_sampled_ranks(x, sa, lcp, samples=400_000, deep_samples=100_000, deep_min_lcp=40)
     assert res["deep_ranks"] > 0 and res["max_lcp_checked"] >= 40_000
     print(f"4.4e9-byte text: {st.ms_total:.0f} ms device total, {res}")
+    # round 5: the same build as TWO shards (what two ranks run): each shard equals its slice of the single build, element for
+    # element, apart from the first LCP of shard 1, which the device stitch sets from the boundary triples
+    from sufr_amd import shards
+    host_sa, host_lcp = sa.cpu(), lcp.cpu()
+    del sa, lcp
+    torch.cuda.empty_cache()
+    off, rows, firsts = 0, [], []
+    out_sa = torch.empty(n // 2 + (1 << 28), dtype=torch.int64, device=dev)
+    out_lcp = torch.empty_like(out_sa)
+    for r in range(2):
+        psa, plcp = db.sort(x, is_dna=True, index_width=8, shard_index=r, num_shards=2, out_sa=out_sa, out_lcp=out_lcp)
+        k = psa.numel()
+        assert k > 0 and torch.equal(psa.cpu(), host_sa[off:off + k]) and torch.equal(plcp[1:].cpu(), host_lcp[off + 1:off + k])
+        rows.append(shards.gather_boundaries_device(psa, k))
+        if r == 1:
+            bounds = torch.cat(rows).contiguous()
+            shards.stitch_device(db.ctx, n, bounds, 1, plcp)
+            db.ctx.synchronize()
+            assert int(plcp[0]) == int(host_lcp[off])
+        off += k
+    assert off == count
+    print(f"4.4e9-byte text as two shards: {db.stats.ms_total:.0f} ms device total for the second shard")
+    del out_sa, out_lcp, psa, plcp, host_sa, host_lcp
     # the same text under the reference's `hu-mask` seed (Makefile:82): windows built with the mask, merged under the masked
     # order.  Sampled neighbours: care symbols in order, equal ones in descending position, LCP = equal care symbols.
-    del sa, lcp
     torch.cuda.empty_cache()
     mask = "111010010100110111"
     try:
@@ -342,3 +364,68 @@ def test_repairs_are_zero_when_the_margin_suffices(oracle):
     sa, lcp, repaired = build_capped(torch.from_numpy(t).cuda(), 5000, 3000, 0, 4, is_dna=True)
     want_sa, want_lcp, _ = oracle.build(t, is_dna=True)
     assert repaired == 0 and np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
+
+
+# ---- round 5: shards of a windowed build --------------------------------------------------------------
+def sharded_windowed(x, n, num_shards, window, margin, index_width, retry=0, **flags):
+    """every shard of a windowed build on one context, one after the other (what the ranks of an N-GPU job run), stitched on
+    the device with the boundary triples in device memory; returns the concatenated arrays, the shard sizes and the repairs"""
+    from sufr_amd import shards
+    db = sufr_amd.DeviceBuilder(0)
+    db.ctx.set_window(window, margin)
+    db.ctx.set_window_retry(retry)
+    parts, rows, repaired = [], [], 0
+    for r in range(num_shards):
+        sa, lcp = db.sort(x, index_width=index_width, shard_index=r, num_shards=num_shards, **flags)
+        repaired += db.ctx.window_repairs
+        parts.append((sa.clone(), lcp.clone()))
+        rows.append(shards.gather_boundaries_device(sa, sa.numel()))
+    bounds = torch.cat(rows).contiguous()
+    for r in range(num_shards):
+        shards.stitch_device(db.ctx, n, bounds, r, parts[r][1])
+    db.ctx.synchronize()
+    sa = torch.cat([p[0] for p in parts]).cpu().numpy(); lcp = torch.cat([p[1] for p in parts]).cpu().numpy()
+    db.close()
+    if index_width == 4:
+        sa, lcp = sa.view(np.uint32), lcp.view(np.uint32)
+    return sa.astype(np.uint64), lcp.astype(np.uint64), [int(p[0].numel()) for p in parts], repaired
+
+
+@pytest.mark.parametrize("index_width", [4, 8])
+@pytest.mark.parametrize("num_shards,window,margin", [(2, 20000, 3000), (3, 7000, 500), (5, 5000, 64), (8, 30000, 100)])
+@pytest.mark.parametrize("flags", [dict(is_dna=True), dict(is_dna=True, allow_ambiguity=True), dict()])
+def test_sharded_windowed_build_concatenates_to_the_oracle(oracle, num_shards, window, margin, index_width, flags):
+    """2 shards x 3 windows (and 3 x 9, 5 x 12, 8 x 2): rounds 2-4 refused a sharded windowed build ("windowed builds are
+    single-GPU").  The shards -- ranges of the first 8 bytes, the same on every rank -- concatenate, after the device stitch of
+    their first LCPs, to the oracle's arrays bit for bit."""
+    t = repeat_text(60_000, 1, 900, 40)
+    want_sa, want_lcp, _ = oracle.build(t, **flags)
+    sa, lcp, sizes, _ = sharded_windowed(torch.from_numpy(t).cuda(), t.size, num_shards, window, margin, index_width, **flags)
+    assert sum(sizes) == want_sa.size and sum(1 for c in sizes if c) >= min(num_shards, 4)      # (DNA: few distinct first bytes)
+    assert np.array_equal(sa, want_sa.astype(np.uint64))
+    assert np.array_equal(lcp, want_lcp.astype(np.uint64))
+
+
+def test_sharded_windowed_build_with_repairs_and_length_cap(oracle):
+    """the shards of a windowed build whose windows need the whole-text repair (re-build margin capped below the repeat), and
+    of a -m 50 build in windows: both concatenate to the one-GPU arrays"""
+    t = repeat_text(60_000, 1, 900, 40)
+    x = torch.from_numpy(t).cuda()
+    want_sa, want_lcp, _ = oracle.build(t, is_dna=True)
+    sa, lcp, sizes, repaired = sharded_windowed(x, t.size, 3, 4096, 64, 8, retry=64, is_dna=True)
+    assert repaired > 0 and np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
+    db = sufr_amd.DeviceBuilder(0)
+    one_sa, one_lcp = (a.cpu().numpy().view(np.uint32).astype(np.uint64) for a in db.sort(x, is_dna=True, max_query_len=50))
+    db.close()
+    sa, lcp, sizes, _ = sharded_windowed(x, t.size, 4, 9000, 100, 4, is_dna=True, max_query_len=50)
+    assert np.array_equal(sa, one_sa) and np.array_equal(lcp, one_lcp)
+
+
+def test_sharded_windowed_seed_mask_is_refused_with_a_message():
+    t = repeat_text(60_000, 1, 900, 40)
+    db = sufr_amd.DeviceBuilder(0)
+    db.ctx.set_window(9000, 100)
+    with pytest.raises(sufr_amd.SufrHipError) as e:
+        db.sort(torch.from_numpy(t).cuda(), is_dna=True, seed_mask="1101", shard_index=1, num_shards=2)
+    assert e.value.code == -6 and "one GPU" in e.value.message
+    db.close()
