@@ -425,6 +425,37 @@ struct LzmaStream {                    // lzma_stream of lzma/base.h (liblzma 5.
     size_t reserved_int3, reserved_int4; int reserved_enum1, reserved_enum2;
 };
 
+// Known-answer streams: the two stream structs above are declared BY HAND, so a library whose layout differs (another major
+// version, another ABI) would otherwise read garbage silently.  Before the first real input each library inflates 60 known
+// bytes through exactly the code path below; anything but those bytes -- and the counters the structs claim to hold -- makes
+// the reader refuse the format with a message.
+const uint8_t KAT_PLAIN[61] = ">kat\nACGTNNNNacgt$%\n>kat\nACGTNNNNacgt$%\n>kat\nACGTNNNNacgt$%\n";
+const uint8_t KAT_BZ2[71] = {66, 90, 104, 57, 49, 65, 89, 38, 83, 89, 113, 179, 145, 152, 0, 0, 8, 223, 128, 64, 16, 6, 0, 0, 1, 40, 129, 4, 0, 40, 136,
+    4, 0, 32, 0, 49, 76, 0, 1, 31, 170, 132, 194, 104, 218, 105, 226, 97, 117, 225, 150, 152, 68, 109, 183, 169, 126, 227, 138, 165, 209, 119, 36,
+    83, 133, 9, 7, 27, 57, 25, 128};
+const uint8_t KAT_XZ[88] = {253, 55, 122, 88, 90, 0, 0, 4, 230, 214, 180, 70, 2, 0, 33, 1, 22, 0, 0, 0, 116, 47, 229, 163, 224, 0, 59, 0, 26, 93, 0, 31,
+    26, 200, 39, 116, 88, 133, 123, 175, 94, 108, 220, 169, 185, 90, 174, 181, 95, 34, 109, 230, 135, 123, 58, 0, 0, 0, 0, 0, 101, 151, 250, 13,
+    141, 141, 9, 53, 0, 1, 54, 60, 217, 88, 245, 134, 31, 182, 243, 125, 1, 0, 0, 0, 0, 4, 89, 90};
+
+bool inflate_bzip2(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::string& why);
+bool inflate_xz(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::string& why);
+// 0: not tried, 1: passed, -1: failed (decided once per process; the test calls the inflater with `src` = the known stream)
+std::atomic<int> g_bz_kat{0}, g_xz_kat{0};
+bool kat_ok(std::atomic<int>& state, bool (*inflate)(const uint8_t*, size_t, std::vector<uint8_t>&, std::string&), const uint8_t* blob, size_t blen,
+            const char* lib, std::string& why)
+{
+    int s = state.load();
+    if (s == 0) {
+        state.store(2);                                          // (the self-test itself runs the inflater: do not recurse)
+        std::vector<uint8_t> got; std::string w;
+        const bool ok = inflate(blob, blen, got, w) && got.size() == 60 && memcmp(got.data(), KAT_PLAIN, 60) == 0;
+        state.store(s = ok ? 1 : -1);
+    }
+    if (s == -1) { why = std::string(lib) + " on this machine does not decode the built-in known-answer stream: its stream struct differs from "
+                         "the one sufr_io.cpp declares -- this input format is refused rather than misread"; return false; }
+    return true;
+}
+
 bool inflate_bzip2(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::string& why)
 {
     void* h = dlopen("libbz2.so.1.0", RTLD_NOW);
@@ -434,6 +465,7 @@ bool inflate_bzip2(const uint8_t* src, size_t len, std::vector<uint8_t>& out, st
     auto run = (int (*)(BzStream*))dlsym(h, "BZ2_bzDecompress");
     auto fini = (int (*)(BzStream*))dlsym(h, "BZ2_bzDecompressEnd");
     if (!init || !run || !fini) { why = "libbz2 lacks the BZ2_bzDecompress interface"; dlclose(h); return false; }
+    if (src != KAT_BZ2 && !kat_ok(g_bz_kat, inflate_bzip2, KAT_BZ2, sizeof KAT_BZ2, "libbz2", why)) { dlclose(h); return false; }
     out.resize(len * 5 + (1u << 20));
     size_t have = 0, at = 0;
     bool ok = true;
@@ -452,6 +484,7 @@ bool inflate_bzip2(const uint8_t* src, size_t len, std::vector<uint8_t>& out, st
             at += in0 - st.avail_in; have += out0 - st.avail_out;
             if (rc == 0 && in0 == st.avail_in && out0 == st.avail_out) { rc = -7; }      // no progress: truncated input
         }
+        if (src == KAT_BZ2 && (st.total_out_lo32 != 60u || st.total_in_lo32 != (unsigned)sizeof KAT_BZ2)) rc = -99;   // (the struct's counters)
         fini(&st);
         if (rc != 4) { why = "corrupt or truncated bzip2 stream"; ok = false; }             // BZ_STREAM_END
         while (ok && at < len && (src[at] == 0)) at++;                                      // padding between streams
@@ -470,6 +503,7 @@ bool inflate_xz(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::
     auto run = (int (*)(LzmaStream*, int))dlsym(h, "lzma_code");
     auto fini = (void (*)(LzmaStream*))dlsym(h, "lzma_end");
     if (!init || !run || !fini) { why = "liblzma lacks the lzma_stream_decoder interface"; dlclose(h); return false; }
+    if (src != KAT_XZ && !kat_ok(g_xz_kat, inflate_xz, KAT_XZ, sizeof KAT_XZ, "liblzma", why)) { dlclose(h); return false; }
     LzmaStream st;
     memset(&st, 0, sizeof st);
     if (init(&st, UINT64_MAX, 0x08u /* LZMA_CONCATENATED */) != 0) { why = "lzma_stream_decoder failed"; dlclose(h); return false; }
@@ -484,6 +518,7 @@ bool inflate_xz(const uint8_t* src, size_t len, std::vector<uint8_t>& out, std::
         rc = run(&st, st.avail_in ? 0 /* LZMA_RUN */ : 3 /* LZMA_FINISH */);
         have += out0 - st.avail_out;
     }
+    if (src == KAT_XZ && (st.total_out != 60u || st.total_in != sizeof KAT_XZ)) rc = -99;     // (the struct's counters)
     fini(&st);
     dlclose(h);
     if (rc != 1) { why = "corrupt or truncated xz stream"; out.clear(); return false; }      // LZMA_STREAM_END

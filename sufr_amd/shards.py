@@ -52,7 +52,7 @@ def stitch_device(ctx, text_len: int, bounds, rank: int, lcp) -> None:
     tensor, on the GPU).  The gather ran on torch's stream, the kernel runs on the context's: wait for the former."""
     from . import _lib
     world = bounds.shape[0]
-    if world == 1 or rank == 0:
+    if world == 1 or rank == 0 or lcp.numel() == 0:           # (an empty shard has no first LCP -- and no array to point at)
         return
     torch.cuda.current_stream(bounds.device).synchronize()
     fn = _lib.lib().sufr_hip_stitch_device_u64 if lcp.dtype == torch.int64 else _lib.lib().sufr_hip_stitch_device_u32

@@ -429,3 +429,16 @@ def test_sharded_windowed_seed_mask_is_refused_with_a_message():
         db.sort(torch.from_numpy(t).cuda(), is_dna=True, seed_mask="1101", shard_index=1, num_shards=2)
     assert e.value.code == -6 and "one GPU" in e.value.message
     db.close()
+
+
+def test_sharded_windowed_build_with_empty_shards(oracle):
+    """a homopolymer: every sampled 8-byte prefix is the same, so all range bounds coincide and most shards are empty -- they
+    build, stitch (nothing to do) and concatenate like the others (profiles/soak_wide.py found the Python stitch passing a null
+    pointer for an empty shard)"""
+    t = np.full(30_001, ord("A"), dtype=np.uint8)
+    t[11_000] = ord("C")
+    t[-1] = ord("$")
+    want_sa, want_lcp, _ = oracle.build(t, is_dna=True)
+    sa, lcp, sizes, _ = sharded_windowed(torch.from_numpy(t).cuda(), t.size, 5, 9_000, 64, 8, is_dna=True)
+    assert sizes.count(0) >= 2 and sum(sizes) == want_sa.size
+    assert np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
