@@ -1245,3 +1245,41 @@ def test_human_config_c4_properties():
         off += k
     assert off == s
     db.close()
+
+
+def test_create_writes_through_links_and_keeps_plain_files_atomic(tmp_path):
+    """`sufr create -o X` (advisor r4, medium): a NEW output and an existing plain file are written as `X.partial` and renamed
+    (the existing file's mode survives, no `.partial` is left behind); a symlink, a hard-linked file and a device node are
+    opened in place, as the reference's File::create does (sufr_builder.rs:819) -- the link stays a link, the other name of a
+    hard-linked file sees the new bytes, `/dev/null` stays a character device."""
+    import stat
+    case = dict(GOLDEN_CASES["2.sufr"])
+    fa = GOLDEN / "inputs" / case.pop("fa")
+    want = (GOLDEN / "expected" / "2.sufr").read_bytes()
+
+    def cli(out):
+        r = subprocess.run([str(sufr_amd.CLI_PATH), "create", "--dna", "-o", str(out), str(fa)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+    new = tmp_path / "new.sufr"
+    cli(new)
+    assert new.read_bytes() == want and not (tmp_path / "new.sufr.partial").exists()
+    plain = tmp_path / "plain.sufr"
+    plain.write_bytes(b"old contents")
+    plain.chmod(0o600)
+    cli(plain)
+    assert plain.read_bytes() == want and stat.S_IMODE(plain.stat().st_mode) == 0o600
+    assert not (tmp_path / "plain.sufr.partial").exists()
+    target = tmp_path / "target.bin"
+    target.write_bytes(b"x")
+    link = tmp_path / "link.sufr"
+    link.symlink_to(target)
+    cli(link)
+    assert link.is_symlink() and target.read_bytes() == want
+    a, b = tmp_path / "a.sufr", tmp_path / "b.sufr"
+    a.write_bytes(b"y")
+    os.link(a, b)
+    cli(a)
+    assert a.read_bytes() == want and b.read_bytes() == want and a.stat().st_ino == b.stat().st_ino
+    cli("/dev/null")
+    assert stat.S_ISCHR(os.stat("/dev/null").st_mode) and not os.path.exists("/dev/null.partial")
