@@ -417,7 +417,8 @@ def _templated_runs_text(seed, nruns, lo, hi, ntemplates=40, tlen=260):
     return np.concatenate(parts)
 
 
-@pytest.mark.parametrize("case", ["n_runs_amb", "g_runs_plain", "n_runs_amb_soft", "two_symbols", "n_runs_amb_3_shards", "templated_tails"])
+@pytest.mark.parametrize("case", ["n_runs_amb", "g_runs_plain", "n_runs_amb_soft", "two_symbols", "n_runs_amb_3_shards", "templated_tails",
+                                  "long_templated_tails"])
 def test_buckets_of_one_repeated_symbol_equal_oracle(oracle, case):
     """A bucket c^21 of a million records and more is ordered in closed form (sufr_runs.inc): only the last member of every run
     goes through the levels, the others are placed by counting -- class 0 / class 1 blocks, the table of levels and the
@@ -428,6 +429,10 @@ def test_buckets_of_one_repeated_symbol_equal_oracle(oracle, case):
         raw = _runs_text(51, 6_000_000, ord("N"), 7000, 21, 900); kw["allow_ambiguity"] = True
     elif case == "templated_tails":
         raw = _templated_runs_text(55, 5200, 6, 760); kw["allow_ambiguity"] = True
+    elif case == "long_templated_tails":
+        # three templates of 3 000 symbols: neighbouring tails agree for 1 500 - 3 000 symbols, beyond the cap of k_rg_fix's walk
+        # (the LCP of a tile's first entry then comes from the minimum of the tail LCPs between the two runs)
+        raw = _templated_runs_text(56, 5200, 6, 760, ntemplates=3, tlen=3000); kw["allow_ambiguity"] = True
     elif case == "g_runs_plain":
         raw = _runs_text(52, 5_000_000, ord("G"), 5000, 18, 700)
     elif case == "n_runs_amb_soft":
