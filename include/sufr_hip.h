@@ -252,7 +252,9 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx *ctx, const sufr_sequence_data *s
  * One process driving N devices: sufr_hip_create_from_sequence_multi / sufr_hip_create_file_multi build shard r
  * of n_ctx on ctxs[r] (a host thread per context; contexts may share a device) and write ONE .sufr file, byte for
  * byte the file of the single-GPU build, --seed-mask and --max-query-len builds included (round 4; a cap below 8
- * symbols and texts that need u64 indices are built on ctxs[0] alone).  stats: n_ctx entries or NULL.
+ * symbols is built on ctxs[0] alone).  Texts that take windows (2^32 - 2^24 bytes and more) are sharded over the contexts
+ * too since round 5 -- shard r of the windowed build on ctxs[r], arrays of the file's index width --, except seed-mask
+ * builds, which ctxs[0] builds alone.  stats: n_ctx entries or NULL.
  *
  * One process per GPU (torch.distributed / MPI ranks): every rank calls sufr_hip_shard_build, the ranks exchange
  * their sufr_shard_info (24 bytes each: the only collective of the path), rank 0 calls sufr_write_frame, and after

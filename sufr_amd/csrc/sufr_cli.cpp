@@ -74,7 +74,8 @@ int usage(FILE* f)
             "      --window <POSITIONS>          Build texts longer than this in overlapping windows merged on the device\n"
             "                                    [default: one window below 2^32 - 2^24 bytes, as few as fit above]\n"
             "      --margin <POSITIONS>          Comparison context after every window [default: 2^26]\n\n"
-            "Texts of 2^32 - 2^24 bytes and more are built in overlapping 32-bit windows merged on the device (one GPU).\n");
+            "Texts of 2^32 - 2^24 bytes and more are built in overlapping 32-bit windows merged on the device; with --devices every\n"
+            "device builds its shard of the windows (a seed mask: on the first device).\n");
     return f == stderr ? 2 : 0;
 }
 

@@ -58,6 +58,7 @@ int sufr_hip_build_u64(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, ui
 // ---- internal hooks of sufr_io.cpp into the pipeline (sufr_capi.inc) ------------------------------------------------
 void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg) { if (ctx) ctx->err = msg ? msg : ""; }
 int sufr_hip_is_wide_(const sufr_hip_ctx*, uint64_t) { return 0; }
+int sufr_hip_ctx_device_(const sufr_hip_ctx*) { return -1; }
 void sufr_hip_release_build_arrays_(sufr_hip_ctx*, int) {}
 int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, uint64_t, const char*, uint32_t, uint32_t,
                              uint64_t*, sufr_hip_stats*, int*, const void**, const void**, const void**) { return no_device(ctx); }

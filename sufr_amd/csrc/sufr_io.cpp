@@ -281,6 +281,7 @@ bool pwrite_all(int fd, const void* buf, size_t len, uint64_t off)
 
 extern "C" void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg);  // sufr_capi.inc
 extern "C" int sufr_hip_is_wide_(const sufr_hip_ctx* ctx, uint64_t n);
+extern "C" int sufr_hip_ctx_device_(const sufr_hip_ctx* ctx);
 extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t flags,
                                         uint64_t max_query_len, const char* seed_mask, uint32_t shard_index,
                                         uint32_t num_shards, uint64_t* num_suffixes, sufr_hip_stats* stats,
@@ -773,6 +774,130 @@ int sufr_hip_shard_write(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const 
     return 0;
 }
 
+// Texts that take windows (2^32 - 2^24 bytes and more, or above the caller's window), several contexts (round 5): shard r of the
+// windowed build (ranges of the first 8 bytes, sufr_wide.inc) is built on ctxs[r] into device arrays of the file's index width,
+// the first LCP of every shard is stitched on its device, and every context streams its slice to its place in the one file.
+static int create_wide_multi(sufr_hip_ctx* const* ctxs, int n_ctx, const sufr_sequence_data& sd, const sufr_create_args* a,
+                             const std::string& outfile, sufr_hip_stats* stats)
+{
+    sufr_hip_ctx* ctx0 = ctxs[0];
+    const uint64_t n = sd.seq_len;
+    const int width = n < 0xFFFFFFFFull ? 4 : 8;               // suffix_array.rs:461
+    const uint32_t flags = build_flags(a);
+    const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
+    struct Shard { void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr, *d_bounds = nullptr; uint64_t s = 0, first = 0, last = 0; int rc = 0, device = 0; sufr_hip_stats st; };
+    std::vector<Shard> sh(n_ctx);
+    auto release = [&]() {
+        for (Shard& x : sh) {
+            if (hipSetDevice(x.device) != hipSuccess) continue;
+            for (void* q : {x.d_text, x.d_sa, x.d_lcp, x.d_bounds}) if (q) (void)hipFree(q);
+            x.d_text = x.d_sa = x.d_lcp = x.d_bounds = nullptr;
+        }
+    };
+    const double t0 = now_s();
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n_ctx; r++)
+            th.emplace_back([&, r]() {
+                Shard& x = sh[r];
+                memset(&x.st, 0, sizeof x.st);
+                x.device = sufr_hip_ctx_device_(ctxs[r]);
+                if (hipSetDevice(x.device) != hipSuccess || hipMalloc(&x.d_text, n + 64) != hipSuccess ||
+                    hipMemcpy(x.d_text, sd.seq, n, hipMemcpyHostToDevice) != hipSuccess) {
+                    sufr_hip_set_error_(ctxs[r], "out of device memory (text of a windowed shard)"); x.rc = SUFR_HIP_E_NOMEM; return;
+                }
+                // a shard holds ~1 / n_ctx of the suffixes; a skewed one gets room for all of them in a second try
+                uint64_t cap = n / (uint64_t)n_ctx * 2 + ((uint64_t)1 << 20);
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    if (cap > n) cap = n;
+                    if (hipMalloc(&x.d_sa, cap * (size_t)width + 16) != hipSuccess || hipMalloc(&x.d_lcp, cap * (size_t)width + 16) != hipSuccess) {
+                        sufr_hip_set_error_(ctxs[r], "out of device memory (arrays of a windowed shard)"); x.rc = SUFR_HIP_E_NOMEM; return;
+                    }
+                    x.rc = width == 4
+                        ? sufr_hip_sort_device_u32(ctxs[r], x.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
+                                                   (uint32_t)r, (uint32_t)n_ctx, x.d_sa, x.d_lcp, cap, &x.s, &x.st)
+                        : sufr_hip_sort_device_u64(ctxs[r], x.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
+                                                   (uint32_t)r, (uint32_t)n_ctx, x.d_sa, x.d_lcp, cap, &x.s, &x.st);
+                    if (x.rc != SUFR_HIP_E_CAPACITY || cap == n) break;
+                    (void)hipFree(x.d_sa); (void)hipFree(x.d_lcp); x.d_sa = x.d_lcp = nullptr;
+                    cap = n;
+                }
+                if (x.rc == 0 && x.s) {
+                    uint64_t f = 0, l = 0;
+                    if (hipMemcpy(&f, x.d_sa, (size_t)width, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(&l, (const uint8_t*)x.d_sa + (x.s - 1) * (size_t)width, (size_t)width, hipMemcpyDeviceToHost) != hipSuccess) {
+                        sufr_hip_set_error_(ctxs[r], "reading a shard's ends failed"); x.rc = SUFR_HIP_E_HIP; return;
+                    }
+                    x.first = f; x.last = l;             // (little-endian: a 4-byte value lands in the low half)
+                }
+            });
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < n_ctx; r++)
+        if (sh[r].rc) { if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r])); const int rc = sh[r].rc; release(); return rc; }
+    const double t_built = now_s();
+    // the boundary triples of all shards, to every device; the stitch under the order of the build (k_lcp_stitch)
+    std::vector<uint64_t> bounds((size_t)n_ctx * 3);
+    std::vector<uint64_t> off(n_ctx, 0);
+    uint64_t total = 0;
+    for (int r = 0; r < n_ctx; r++) { bounds[3 * r] = sh[r].first; bounds[3 * r + 1] = sh[r].last; bounds[3 * r + 2] = sh[r].s; off[r] = total; total += sh[r].s; }
+    for (int r = 1; r < n_ctx; r++) {
+        Shard& x = sh[r];
+        if (!x.s) continue;
+        int rc = 0;
+        if (hipSetDevice(x.device) != hipSuccess || hipMalloc(&x.d_bounds, bounds.size() * 8) != hipSuccess ||
+            hipMemcpy(x.d_bounds, bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = SUFR_HIP_E_HIP;
+        if (!rc) rc = width == 4 ? sufr_hip_stitch_device_u32(ctxs[r], n, (const uint64_t*)x.d_bounds, (uint32_t)r, (uint32_t)n_ctx, x.d_lcp)
+                                 : sufr_hip_stitch_device_u64(ctxs[r], n, (const uint64_t*)x.d_bounds, (uint32_t)r, (uint32_t)n_ctx, x.d_lcp);
+        if (rc) { if (rc == SUFR_HIP_E_HIP) sufr_hip_set_error_(ctx0, "stitching a windowed shard failed"); else sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r])); release(); return rc; }
+    }
+    // the file: header and name table, the normalised text from the host, every shard's slices from its device
+    const SufrLayout L = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, width, total, a->has_max_query_len, a->max_query_len,
+                                     a->seed_mask, sd.start_positions, sd.num_sequences, (const char* const*)sd.sequence_names);
+    struct stat ost;
+    const int lrc = lstat(outfile.c_str(), &ost);
+    const bool in_place = lrc == 0 ? !(S_ISREG(ost.st_mode) && ost.st_nlink == 1) : errno != ENOENT;      // (see sufr_hip_create_from_sequence_multi)
+    const std::string partial = in_place ? outfile : outfile + ".partial";
+    int fd = ::open(partial.c_str(), O_WRONLY | O_CREAT | O_TRUNC, lrc == 0 && !in_place ? (ost.st_mode & 07777) : 0644);
+    if (fd < 0) { sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str()); release(); return SUFR_HIP_E_IO; }
+    bool ok = pwrite_all(fd, L.head.data(), L.head.size(), 0) && pwrite_all(fd, L.tail.data(), L.tail.size(), L.tail_pos);
+    {
+        const uint64_t PIECE = (uint64_t)32 << 20;
+        std::vector<uint8_t> buf(PIECE);
+        for (uint64_t o = 0; ok && o < n; o += PIECE) {
+            const uint64_t len = n - o < PIECE ? n - o : PIECE;
+            (void)sufr_hip_normalize(sd.seq + o, buf.data(), len, a->ignore_softmask);
+            ok = pwrite_all(fd, buf.data(), len, L.text_pos + o);
+        }
+    }
+    int failed = 0;
+    for (int r = 0; ok && !failed && r < n_ctx; r++) {
+        if (!sh[r].s) continue;
+        std::vector<Section> secs;
+        secs.push_back({sh[r].d_sa, sh[r].s * (uint64_t)width, L.sa_pos + off[r] * (uint64_t)width});
+        secs.push_back({sh[r].d_lcp, sh[r].s * (uint64_t)width, L.lcp_pos + off[r] * (uint64_t)width});
+        failed = stream_sections(sh[r].device, fd, secs);
+    }
+    if (close(fd) != 0) ok = false;
+    release();
+    if (!ok || failed) {
+        if (!in_place) (void)unlink(partial.c_str());
+        sufr_hip_set_error_(ctx0, failed == 1 ? "device-to-host copy of the arrays failed" : (outfile + ": write failed").c_str());
+        return failed == 1 ? SUFR_HIP_E_HIP : SUFR_HIP_E_IO;
+    }
+    if (!in_place && rename(partial.c_str(), outfile.c_str()) != 0) {
+        sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str());
+        (void)unlink(partial.c_str());
+        return SUFR_HIP_E_IO;
+    }
+    if (stats)
+        for (int r = 0; r < n_ctx; r++) {
+            stats[r] = sh[r].st;
+            stats[r].host_read_s = 0.0f; stats[r].host_build_s = (float)(t_built - t0); stats[r].host_write_s = (float)(now_s() - t_built);
+        }
+    return 0;
+}
+
 // One process, several GPUs: shard r of n_ctx is built on ctxs[r] (a thread per context), then every context
 // streams its SA / LCP slice to  sa_pos + 4 * (suffixes of the shards before it)  -- the multi-writer form of
 // SufrBuilder::write (sufr_builder.rs:875-906); the first LCP of every shard but the first is the boundary fix
@@ -787,8 +912,16 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
     const sufr_sequence_data& sd = *sdp;
     const std::string outfile = output_name(a);
     if (path_out && path_out_len) snprintf(path_out, path_out_len, "%s", outfile.c_str());
-    if (sufr_hip_is_wide_(ctx0, sd.seq_len))               // windowed build: one GPU, host buffers
-        return sufr_hip_create_from_sequence(ctx0, sdp, a, path_out, path_out_len, stats);
+    if (sufr_hip_is_wide_(ctx0, sd.seq_len)) {
+        // windowed build: its shards over the contexts (round 5); a seed mask or a cap below 8 symbols is not sharded in windows,
+        // and one context takes the host-buffer path
+        bool all_wide = true;
+        for (int r = 0; r < n_ctx; r++) all_wide = all_wide && sufr_hip_is_wide_(ctxs[r], sd.seq_len);
+        if (n_ctx == 1 || !all_wide || a->seed_mask || (a->has_max_query_len && a->max_query_len < 8))
+            return sufr_hip_create_from_sequence(ctx0, sdp, a, path_out, path_out_len, stats);
+        if (a->has_max_query_len && a->seed_mask) { sufr_hip_set_error_(ctx0, "Cannot use max_query_len and seed_mask together"); return SUFR_HIP_E_CONFLICT; }
+        return create_wide_multi(ctxs, n_ctx, sd, a, outfile, stats);
+    }
     if (a->has_max_query_len && a->max_query_len < 8) n_ctx = 1;   // (a cap shorter than a first digit ties suffixes across shards)
     if (a->has_max_query_len && a->seed_mask) {            // clap's conflicts_with; builder check 163-165 (before the file is touched)
         sufr_hip_set_error_(ctx0, "Cannot use max_query_len and seed_mask together");

@@ -442,3 +442,41 @@ def test_sharded_windowed_build_with_empty_shards(oracle):
     sa, lcp, sizes, _ = sharded_windowed(torch.from_numpy(t).cuda(), t.size, 5, 9_000, 64, 8, is_dna=True)
     assert sizes.count(0) >= 2 and sum(sizes) == want_sa.size
     assert np.array_equal(sa, want_sa.astype(np.uint64)) and np.array_equal(lcp, want_lcp.astype(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["long_dna_sequence.sufr", "long_dna_sequence_allow_ambiguity.sufr", "uniprot.sufr", "2.sufr"])
+def test_cli_create_in_windows_over_several_contexts_writes_the_golden_file(tmp_path, name):
+    """`sufr --devices 0,0,0 create --window`: the shards of a windowed build, one per context, stream their slices into the one
+    file (round 5: rounds 2-4 built such texts on the first device alone) -- the reference's golden file byte for byte"""
+    case = GOLDEN_CASES[name]
+    out = tmp_path / name
+    n = (GOLDEN / "expected" / name).stat().st_size
+    args = [str(sufr_amd.CLI_PATH), "--devices", "0,0,0", "create", str(GOLDEN / "inputs" / case["fa"]), "-o", str(out), "-n", "16", "-r", "42",
+            "--window", str(max(16, n // 40)), "--margin", "48"]
+    if case.get("is_dna"):
+        args.append("-d")
+    if case.get("allow_ambiguity"):
+        args.append("-a")
+    if case.get("ignore_softmask"):
+        args.append("-i")
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == (GOLDEN / "expected" / name).read_bytes()
+    assert not (tmp_path / (name + ".partial")).exists()
+
+
+def test_cli_windowed_create_over_contexts_equals_the_one_context_file(tmp_path):
+    """a 60 kb text with repeats across every window boundary, plain and -m 40: two and five contexts write the file one context
+    writes (the first LCP of every shard stitched on its device under the order of the build)"""
+    t = repeat_text(60_000, 9, 900, 40)
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b">r\n" + t[:-1].tobytes() + b"\n")
+    for extra in ([], ["-m", "40"]):
+        files = []
+        for devs in ("0", "0,0", "0,0,0,0,0"):
+            out = tmp_path / f"o_{devs.count(',')}_{len(extra)}.sufr"
+            r = subprocess.run([str(sufr_amd.CLI_PATH), "--devices", devs, "create", "-d", str(fa), "-o", str(out), "--window", "7000",
+                                "--margin", "300"] + extra, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            files.append(out.read_bytes())
+        assert files[0] == files[1] == files[2]
