@@ -33,6 +33,71 @@ k_scatter(Rec* __restrict__ out, const uint32_t* __restrict__ bucket_base, uint3
     }
 }
 
+// The direct pattern with the workgroups of an XCD IN LOCKSTEP (round 5, a hypothesis): every tile's stores sweep the bins in
+// order; if the 64 workgroups of a group (= one XCD) start their tiles together, a bin's 64 adjacent runs (64 x r records: the
+// claims on a (group, bin) cursor are adjacent) land in that XCD's L2 within a short window, complete whole kilobytes there and
+// leave for HBM together -- long runs without longer tiles.  A barrier per tile among the co-resident workgroups of a group:
+// one atomic counter per group (a line of its own), spinning with s_sleep.  The grid must be resident as a whole (512 workgroups
+// of 1 024 threads = two per CU).
+__global__ void __launch_bounds__(1024)
+k_scatter_lockstep(Rec* __restrict__ out, const uint32_t* __restrict__ bucket_base, uint32_t* __restrict__ cursor, uint32_t NB, uint32_t r,
+                   uint32_t tiles, uint32_t* __restrict__ gbar, uint32_t nsync)
+{
+    // nsync = barriers per tile: 0 = none (the control: the same persistent grid, unsynchronised), 1 = one before the stores,
+    // k > 1 = one before each k-th of the bin sweep
+    extern __shared__ uint32_t s_base[];
+    const uint32_t g = blockIdx.x & 7u, per_group = gridDim.x >> 3;
+    uint32_t epoch = 0;
+    const uint32_t iters = (tiles + gridDim.x - 1) / gridDim.x;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t t = it * gridDim.x + blockIdx.x;
+        __syncthreads();
+        if (t < tiles)
+            for (uint32_t d = threadIdx.x; d < NB; d += 1024) s_base[d] = bucket_base[d] + atomicAdd(&cursor[(size_t)g * NB + d], r);
+        __syncthreads();
+        const uint32_t total = NB * r, parts = nsync ? nsync : 1u;
+        for (uint32_t q = 0; q < parts; q++) {
+            if (nsync) {
+                epoch++;
+                if (threadIdx.x == 0) {              // the group's workgroups start (this part of) their stores together
+                    atomicAdd(&gbar[g * 64u], 1u);
+                    while (__hip_atomic_load(&gbar[g * 64u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * per_group) __builtin_amdgcn_s_sleep(2);
+                }
+                __syncthreads();
+            }
+            if (t < tiles) {
+                const uint32_t lo = (uint32_t)((uint64_t)total * q / parts), hi = (uint32_t)((uint64_t)total * (q + 1) / parts);
+                for (uint32_t j = lo + threadIdx.x; j < hi; j += 1024) {
+                    const uint32_t d = j / r, o = j - d * r;
+                    out[(size_t)s_base[d] + o] = Rec{j, t, d};
+                }
+            }
+        }
+    }
+}
+
+// The reverse walk: one resident workgroup per (XCD, bin-group) pulls the bin's records from tile-ordered staging (each tile's
+// run of r records sits at tile * NB * r + d * r, i.e. the reads are the scattered side) and writes them contiguously.  Reads are
+// sector-granular and clean, so if the asymmetry between scattered reads and scattered writes is large this ordering wins.
+__global__ void __launch_bounds__(1024)
+k_gather_runs(Rec* __restrict__ out, const Rec* __restrict__ in, uint32_t NB, uint32_t r, uint32_t tiles)
+{
+    // workgroup b owns bins b, b + grid, ...; wave w takes tiles w, w + 16, ...; a wave reads r records of a tile's run per step
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t d = blockIdx.x; d < NB; d += gridDim.x) {
+        const size_t obase = (size_t)d * tiles * r;
+        // 64 lanes cover floor(64 / r) runs at once
+        const uint32_t per = 64u / r, sub = lane / r, o = lane - sub * r;
+        for (uint32_t t0 = wave * per; t0 < tiles; t0 += 16u * per) {
+            const uint32_t t = t0 + sub;
+            if (sub < per && t < tiles) {
+                const Rec v = in[(size_t)t * NB * r + (size_t)d * r + o];
+                out[obase + (size_t)t * r + o] = v;
+            }
+        }
+    }
+}
+
 // XCD-local write combining (the micro-benchmark).  Per (group = XCD, bin) a staging block of
 // BLK records in global memory that is only ever touched by that XCD (so it lives in that XCD's L2: 2 700 x 1 152 B = 3.1 MB of
 // 4 MB); a tile APPENDS its r-record run to the block (returning atomic on the staging cursor, wrap-around inside the block) and
@@ -133,6 +198,51 @@ int main(int argc, char** argv)
         const double runs = (double)tiles * NB, lines = written * 12.0 / 64.0 + runs * (1.0 - 12.0 / 64.0) * 0.0;   // (lower bound: payload / 64)
         printf("bins %5u  run %4u rec (%5u B): %7.2f ms  %6.0f GB/s  >= %5.1f G lines/s  (%.3g runs)\n", NB, r, r * 12, best,
                written * 12.0 / best / 1e6, lines / best / 1e6, runs);
+    }
+    // ---- the reverse walk: scattered READS of r-record runs, contiguous writes ----
+    {
+        Rec* in; CK(hipMalloc(&in, records * sizeof(Rec)));
+        CK(hipMemset(in, 1, records * sizeof(Rec)));
+        for (uint32_t r : {6u, 12u, 24u}) {
+            const uint32_t tiles = (uint32_t)(records / ((uint64_t)NB * r));
+            for (uint32_t ggrid : {512u, 1024u, 2700u}) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; rep++) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_gather_runs, dim3(ggrid), dim3(1024), 0, 0, out, in, NB, r, tiles);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+                }
+                printf("gather-runs bins %5u  run %4u rec (%5u B)  grid %4u: %7.2f ms (read %.1f GB scattered + write %.1f GB contiguous)\n", NB, r, r * 12, ggrid, best,
+                       (double)tiles * NB * r * 12 / 1e9, (double)tiles * NB * r * 12 / 1e9);
+            }
+        }
+        CK(hipFree(in));
+    }
+    // ---- the direct pattern, the workgroups of an XCD in lockstep ----
+    {
+        uint32_t* gbar; CK(hipMalloc(&gbar, 8 * 64 * 4));
+        for (uint32_t r : {6u, 12u, 24u}) {
+            const uint32_t tiles = (uint32_t)(records / ((uint64_t)NB * r));
+            std::vector<uint32_t> hb(NB);
+            for (uint32_t d = 0; d < NB; d++) hb[d] = (uint32_t)((uint64_t)d * tiles * r);
+            CK(hipMemcpy(base, hb.data(), (size_t)NB * 4, hipMemcpyHostToDevice));
+            for (uint32_t lgrid : {512u, 256u}) for (uint32_t nsync : {0u, 1u, 4u, 16u}) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 3; rep++) {
+                    std::vector<uint32_t> hc((size_t)8 * NB, 0u);
+                    const uint32_t per_group = (tiles + 7) / 8 * r;
+                    for (uint32_t g = 0; g < 8; g++) for (uint32_t d = 0; d < NB; d++) hc[(size_t)g * NB + d] = g * per_group;
+                    CK(hipMemcpy(cursor, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+                    CK(hipMemset(gbar, 0, 8 * 64 * 4));
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_scatter_lockstep, dim3(lgrid), dim3(1024), (size_t)NB * 4, 0, out, base, cursor, NB, r, tiles, gbar, nsync);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+                }
+                printf("lockstep bins %5u  run %4u rec (%5u B)  grid %3u (%u workgroups per XCD), %2u barriers per tile: %7.2f ms\n", NB, r, r * 12, lgrid, lgrid / 8, nsync, best);
+            }
+        }
     }
     // ---- XCD-local write combining: r = 12 records per append (the stand-in's pattern), blocks of BLK records ----
     {
