@@ -24,9 +24,12 @@ int no_device(sufr_hip_ctx* ctx) { if (ctx) ctx->err = NO_DEVICE; return SUFR_HI
 
 extern "C" {
 
-// ---- HIP runtime entry points sufr_io.cpp references (pinned staging buffers, copy streams of the writers) ----------
+// ---- HIP runtime entry points sufr_io.cpp references (pinned staging buffers, copy streams of the writers, the per-device arrays of the multi-context windowed create) ----------
 hipError_t hipHostMalloc(void** p, size_t, unsigned int) { if (p) *p = nullptr; return hipErrorNoDevice; }
 hipError_t hipHostFree(void*) { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t) { if (p) *p = nullptr; return hipErrorNoDevice; }
+hipError_t hipFree(void*) { return hipSuccess; }
+hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind) { return hipErrorNoDevice; }
 hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t) { return hipErrorNoDevice; }
 hipError_t hipSetDevice(int) { return hipErrorNoDevice; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { if (s) *s = nullptr; return hipErrorNoDevice; }
