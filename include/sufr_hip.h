@@ -119,6 +119,14 @@ int  sufr_hip_set_window(sufr_hip_ctx *ctx, uint64_t window, uint64_t margin);
 int  sufr_hip_set_window_retry(sufr_hip_ctx *ctx, uint64_t widest_margin);
 /* suffixes of the context's last windowed build that were ordered by whole-text comparison (0: no window needed it) */
 uint64_t sufr_hip_window_repairs(const sufr_hip_ctx *ctx);
+/* Out-of-core form of a windowed `create` (sufr_hip_create_file / _from_sequence / _multi; the counterpart of the reference's
+ * partitions sorted one at a time out of temporary files, sufr_builder.rs:495-598 + write() 875-906): `bytes` = device memory
+ * the suffix and LCP arrays may occupy at once.  The build then runs in ceil(2 * n * width / bytes) shards (ranges of the first
+ * 8 bytes), one after another on every context, and each shard's slice is streamed to its place in the file before the next is
+ * built -- the whole arrays are never resident, on the device or the host.  0 (the default): no limit set; a create whose
+ * arrays do not fit beside the windows' workspace falls back to 2, 4, 8 ... shards by itself.  The price is one windowed
+ * sort of the text per shard.  Seed-mask builds and max_query_len < 8 are not sharded (they keep the whole-array path). */
+int  sufr_hip_set_array_budget(sufr_hip_ctx *ctx, uint64_t bytes);
 
 /* ---- text normalisation: sufr_builder.rs:144-160 (host helper; the GPU build can also do it) --- */
 int sufr_hip_normalize(const uint8_t *in, uint8_t *out, uint64_t n, int ignore_softmask);

@@ -79,7 +79,7 @@ FLAG_SA_U64 = 0x200               # sufr_hip_index_wrap only: 64-bit suffix arra
 # every symbol include/sufr_hip.h declares
 EXPORTS = [
     "sufr_hip_abi_version", "sufr_hip_device_count", "sufr_hip_create", "sufr_hip_destroy",
-    "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_synchronize", "sufr_hip_set_window", "sufr_hip_set_window_retry", "sufr_hip_window_repairs", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
+    "sufr_hip_last_error", "sufr_hip_set_stream", "sufr_hip_synchronize", "sufr_hip_set_window", "sufr_hip_set_window_retry", "sufr_hip_set_array_budget", "sufr_hip_window_repairs", "sufr_hip_normalize", "sufr_hip_sort_device_u32",
     "sufr_hip_sort_device_u64", "sufr_hip_stitch_device_u32", "sufr_hip_stitch_device_u64", "sufr_hip_build_u32", "sufr_hip_build_u64", "sufr_hip_lcp_pair",
     "sufr_read_sequence_file", "sufr_sequence_data_free", "sufr_write_file", "sufr_hip_create_file", "sufr_hip_create_from_sequence",
     "sufr_hip_shard_build", "sufr_write_frame", "sufr_hip_shard_write", "sufr_hip_create_from_sequence_multi",
@@ -144,6 +144,7 @@ def lib() -> C.CDLL:
     L.sufr_hip_synchronize.argtypes = [vp]; L.sufr_hip_synchronize.restype = C.c_int
     L.sufr_hip_set_window.argtypes = [vp, u64, u64]; L.sufr_hip_set_window.restype = C.c_int
     L.sufr_hip_set_window_retry.argtypes = [vp, u64]; L.sufr_hip_set_window_retry.restype = C.c_int
+    L.sufr_hip_set_array_budget.argtypes = [vp, u64]; L.sufr_hip_set_array_budget.restype = C.c_int
     L.sufr_hip_window_repairs.argtypes = [vp]; L.sufr_hip_window_repairs.restype = u64
     L.sufr_hip_normalize.argtypes = [vp, vp, u64, C.c_int]; L.sufr_hip_normalize.restype = C.c_int
     dev_sig = [vp, vp, u64, u32, u64, cp, u64, u64, u32, u32, vp, vp, u64, C.POINTER(u64), C.POINTER(Stats)]
@@ -237,6 +238,10 @@ class Context:
     def set_window_retry(self, widest_margin: int = 0):
         """Cap of the margin a window is re-built with when a repeat crosses its end (0: what 32 bits allow)."""
         self.check(lib().sufr_hip_set_window_retry(self._h, widest_margin))
+
+    def set_array_budget(self, nbytes: int = 0):
+        """Out-of-core windowed create: device bytes the SA + LCP arrays may take at once (sufr_hip_set_array_budget; 0: no limit)."""
+        self.check(lib().sufr_hip_set_array_budget(self._h, nbytes))
 
     @property
     def window_repairs(self) -> int:

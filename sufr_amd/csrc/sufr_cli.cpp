@@ -73,7 +73,10 @@ int usage(FILE* f)
             "  -r, --random-seed <RANDSEED>      Random seed [default: 42]\n"
             "      --window <POSITIONS>          Build texts longer than this in overlapping windows merged on the device\n"
             "                                    [default: one window below 2^32 - 2^24 bytes, as few as fit above]\n"
-            "      --margin <POSITIONS>          Comparison context after every window [default: 2^26]\n\n"
+            "      --margin <POSITIONS>          Comparison context after every window [default: 2^26]\n"
+            "      --array-budget <BYTES>        Windowed builds: device memory the suffix + LCP arrays may take at once; the build\n"
+            "                                    runs shard after shard and streams every slice to the file [default: no limit;\n"
+            "                                    arrays that do not fit are split by themselves]\n\n"
             "Texts of 2^32 - 2^24 bytes and more are built in overlapping 32-bit windows merged on the device; with --devices every\n"
             "device builds its shard of the windows (a seed mask: on the first device).\n");
     return f == stderr ? 2 : 0;
@@ -447,7 +450,7 @@ int main(int argc, char** argv)
     std::string log_file, input, output, seed_mask, delim = "%";
     int device = 0;
     std::vector<int> devices;
-    uint64_t window = 0, margin = 0;
+    uint64_t window = 0, margin = 0, array_budget = 0;
     bool have_cmd = false, have_output = false, have_mask = false;
     int threads = 0;
     sufr_create_args a;
@@ -501,6 +504,7 @@ int main(int argc, char** argv)
         else if (s == "-s" || s == "--seed-mask") { seed_mask = need(i, "-s"); have_mask = true; }
         else if (s == "-r" || s == "--random-seed") a.random_seed = strtoull(need(i, "-r"), nullptr, 10);
         else if (s == "--window") window = strtoull(need(i, "--window"), nullptr, 10);
+        else if (s == "--array-budget") array_budget = strtoull(need(i, "--array-budget"), nullptr, 10);
         else if (s == "--margin") margin = strtoull(need(i, "--margin"), nullptr, 10);
         else if (!s.empty() && s[0] == '-' && s.size() > 1) { fprintf(stderr, "error: unexpected argument '%s'\n", s.c_str()); return 2; }
         else if (input.empty()) input = s;
@@ -560,6 +564,7 @@ int main(int argc, char** argv)
         log.info(std::string("Using HIP device") + (devices.size() > 1 ? "s " : " ") + ids);
     }
     if (window || margin) for (auto* c : ctxs) sufr_hip_set_window(c, window, margin);
+    if (array_budget) sufr_hip_set_array_budget(ctxs[0], array_budget);
     char path[4096];
     std::vector<sufr_hip_stats> sts(devices.size());
     memset(sts.data(), 0, sts.size() * sizeof(sufr_hip_stats));

@@ -27,6 +27,7 @@ extern "C" {
 // ---- HIP runtime entry points sufr_io.cpp references (pinned staging buffers, copy streams of the writers, the per-device arrays of the multi-context windowed create) ----------
 hipError_t hipHostMalloc(void** p, size_t, unsigned int) { if (p) *p = nullptr; return hipErrorNoDevice; }
 hipError_t hipHostFree(void*) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "no device"; }
 hipError_t hipMalloc(void** p, size_t) { if (p) *p = nullptr; return hipErrorNoDevice; }
 hipError_t hipFree(void*) { return hipSuccess; }
 hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind) { return hipErrorNoDevice; }
@@ -46,6 +47,7 @@ int sufr_hip_set_stream(sufr_hip_ctx* ctx, void*) { return no_device(ctx); }
 int sufr_hip_synchronize(sufr_hip_ctx* ctx) { return no_device(ctx); }
 int sufr_hip_set_window(sufr_hip_ctx* ctx, uint64_t, uint64_t) { return no_device(ctx); }
 int sufr_hip_set_window_retry(sufr_hip_ctx* ctx, uint64_t) { return no_device(ctx); }
+int sufr_hip_set_array_budget(sufr_hip_ctx* ctx, uint64_t) { return no_device(ctx); }
 uint64_t sufr_hip_window_repairs(const sufr_hip_ctx*) { return 0; }
 int sufr_hip_sort_device_u32(sufr_hip_ctx* ctx, const void*, uint64_t, uint32_t, uint64_t, const char*, uint64_t, uint64_t,
                              uint32_t, uint32_t, void*, void*, uint64_t, uint64_t*, sufr_hip_stats*) { return no_device(ctx); }
@@ -62,6 +64,7 @@ int sufr_hip_build_u64(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, ui
 void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg) { if (ctx) ctx->err = msg ? msg : ""; }
 int sufr_hip_is_wide_(const sufr_hip_ctx*, uint64_t) { return 0; }
 int sufr_hip_ctx_device_(const sufr_hip_ctx*) { return -1; }
+uint64_t sufr_hip_array_budget_(const sufr_hip_ctx*) { return 0; }
 void sufr_hip_release_build_arrays_(sufr_hip_ctx*, int) {}
 int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, uint64_t, const char*, uint32_t, uint32_t,
                              uint64_t*, sufr_hip_stats*, int*, const void**, const void**, const void**) { return no_device(ctx); }

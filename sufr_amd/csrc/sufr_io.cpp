@@ -282,6 +282,7 @@ bool pwrite_all(int fd, const void* buf, size_t len, uint64_t off)
 extern "C" void sufr_hip_set_error_(sufr_hip_ctx* ctx, const char* msg);  // sufr_capi.inc
 extern "C" int sufr_hip_is_wide_(const sufr_hip_ctx* ctx, uint64_t n);
 extern "C" int sufr_hip_ctx_device_(const sufr_hip_ctx* ctx);
+extern "C" uint64_t sufr_hip_array_budget_(const sufr_hip_ctx* ctx);
 extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, uint64_t n, uint32_t flags,
                                         uint64_t max_query_len, const char* seed_mask, uint32_t shard_index,
                                         uint32_t num_shards, uint64_t* num_suffixes, sufr_hip_stats* stats,
@@ -774,128 +775,225 @@ int sufr_hip_shard_write(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const 
     return 0;
 }
 
-// Texts that take windows (2^32 - 2^24 bytes and more, or above the caller's window), several contexts (round 5): shard r of the
-// windowed build (ranges of the first 8 bytes, sufr_wide.inc) is built on ctxs[r] into device arrays of the file's index width,
-// the first LCP of every shard is stitched on its device, and every context streams its slice to its place in the one file.
-static int create_wide_multi(sufr_hip_ctx* const* ctxs, int n_ctx, const sufr_sequence_data& sd, const sufr_create_args* a,
-                             const std::string& outfile, sufr_hip_stats* stats)
+// Texts that take windows (2^32 - 2^24 bytes and more, or above the caller's window) in K >= n_ctx shards (round 5): shard r of
+// the windowed build (ranges of the first 8 bytes, sufr_wide.inc) is built on ctxs[r % n_ctx] into device arrays of the file's
+// index width, its first LCP is stitched on its device, and its slice is streamed to its place in the one file; the contexts
+// take the shards in rounds of n_ctx.  K > n_ctx is the OUT-OF-CORE form of the build: the suffix and LCP
+// arrays of the whole text are never in HBM together -- a device holds the text, the windows' workspace and ONE shard's arrays,
+// which leave for the file before the next shard is built (the reference's counterpart: partitions sorted one at a time out of
+// temporary files, sufr_builder.rs:495-598, concatenated by write() 875-906).  The price is a windowed sort of the text per
+// shard -- seconds -- against the minutes the file takes to write.  The section offsets need the number of suffixes before the
+// first shard exists: it is counted on the host while the text section is normalised and written (eligibility 446-449 is a
+// property of the normalised byte), and checked against the shards' sum at the end.
+static int create_wide_sharded(sufr_hip_ctx* const* ctxs, int n_ctx, uint32_t K, const sufr_sequence_data& sd, const sufr_create_args* a,
+                               const std::string& outfile, sufr_hip_stats* stats)
 {
     sufr_hip_ctx* ctx0 = ctxs[0];
     const uint64_t n = sd.seq_len;
     const int width = n < 0xFFFFFFFFull ? 4 : 8;               // suffix_array.rs:461
     const uint32_t flags = build_flags(a);
     const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
-    struct Shard { void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr, *d_bounds = nullptr; uint64_t s = 0, first = 0, last = 0; int rc = 0, device = 0; sufr_hip_stats st; };
-    std::vector<Shard> sh(n_ctx);
+    struct Dev { void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr, *d_bounds = nullptr; uint64_t cap = 0, s = 0; int rc = 0, device = 0; sufr_hip_stats st; };
+    std::vector<Dev> dv(n_ctx);
     auto release = [&]() {
-        for (Shard& x : sh) {
+        for (Dev& x : dv) {
             if (hipSetDevice(x.device) != hipSuccess) continue;
             for (void* q : {x.d_text, x.d_sa, x.d_lcp, x.d_bounds}) if (q) (void)hipFree(q);
             x.d_text = x.d_sa = x.d_lcp = x.d_bounds = nullptr;
         }
     };
     const double t0 = now_s();
-    {
-        std::vector<std::thread> th;
-        for (int r = 0; r < n_ctx; r++)
-            th.emplace_back([&, r]() {
-                Shard& x = sh[r];
-                memset(&x.st, 0, sizeof x.st);
-                x.device = sufr_hip_ctx_device_(ctxs[r]);
-                if (hipSetDevice(x.device) != hipSuccess || hipMalloc(&x.d_text, n + 64) != hipSuccess ||
-                    hipMemcpy(x.d_text, sd.seq, n, hipMemcpyHostToDevice) != hipSuccess) {
-                    sufr_hip_set_error_(ctxs[r], "out of device memory (text of a windowed shard)"); x.rc = SUFR_HIP_E_NOMEM; return;
-                }
-                // a shard holds ~1 / n_ctx of the suffixes; a skewed one gets room for all of them in a second try
-                uint64_t cap = n / (uint64_t)n_ctx * 2 + ((uint64_t)1 << 20);
-                for (int attempt = 0; attempt < 2; attempt++) {
-                    if (cap > n) cap = n;
-                    if (hipMalloc(&x.d_sa, cap * (size_t)width + 16) != hipSuccess || hipMalloc(&x.d_lcp, cap * (size_t)width + 16) != hipSuccess) {
-                        sufr_hip_set_error_(ctxs[r], "out of device memory (arrays of a windowed shard)"); x.rc = SUFR_HIP_E_NOMEM; return;
-                    }
-                    x.rc = width == 4
-                        ? sufr_hip_sort_device_u32(ctxs[r], x.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
-                                                   (uint32_t)r, (uint32_t)n_ctx, x.d_sa, x.d_lcp, cap, &x.s, &x.st)
-                        : sufr_hip_sort_device_u64(ctxs[r], x.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
-                                                   (uint32_t)r, (uint32_t)n_ctx, x.d_sa, x.d_lcp, cap, &x.s, &x.st);
-                    if (x.rc != SUFR_HIP_E_CAPACITY || cap == n) break;
-                    (void)hipFree(x.d_sa); (void)hipFree(x.d_lcp); x.d_sa = x.d_lcp = nullptr;
-                    cap = n;
-                }
-                if (x.rc == 0 && x.s) {
-                    uint64_t f = 0, l = 0;
-                    if (hipMemcpy(&f, x.d_sa, (size_t)width, hipMemcpyDeviceToHost) != hipSuccess ||
-                        hipMemcpy(&l, (const uint8_t*)x.d_sa + (x.s - 1) * (size_t)width, (size_t)width, hipMemcpyDeviceToHost) != hipSuccess) {
-                        sufr_hip_set_error_(ctxs[r], "reading a shard's ends failed"); x.rc = SUFR_HIP_E_HIP; return;
-                    }
-                    x.first = f; x.last = l;             // (little-endian: a 4-byte value lands in the low half)
-                }
-            });
-        for (auto& t : th) t.join();
-    }
-    for (int r = 0; r < n_ctx; r++)
-        if (sh[r].rc) { if (r) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r])); const int rc = sh[r].rc; release(); return rc; }
-    const double t_built = now_s();
-    // the boundary triples of all shards, to every device; the stitch under the order of the build (k_lcp_stitch)
-    std::vector<uint64_t> bounds((size_t)n_ctx * 3);
-    std::vector<uint64_t> off(n_ctx, 0);
-    uint64_t total = 0;
-    for (int r = 0; r < n_ctx; r++) { bounds[3 * r] = sh[r].first; bounds[3 * r + 1] = sh[r].last; bounds[3 * r + 2] = sh[r].s; off[r] = total; total += sh[r].s; }
-    for (int r = 1; r < n_ctx; r++) {
-        Shard& x = sh[r];
-        if (!x.s) continue;
-        int rc = 0;
-        if (hipSetDevice(x.device) != hipSuccess || hipMalloc(&x.d_bounds, bounds.size() * 8) != hipSuccess ||
-            hipMemcpy(x.d_bounds, bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = SUFR_HIP_E_HIP;
-        if (!rc) rc = width == 4 ? sufr_hip_stitch_device_u32(ctxs[r], n, (const uint64_t*)x.d_bounds, (uint32_t)r, (uint32_t)n_ctx, x.d_lcp)
-                                 : sufr_hip_stitch_device_u64(ctxs[r], n, (const uint64_t*)x.d_bounds, (uint32_t)r, (uint32_t)n_ctx, x.d_lcp);
-        if (rc) { if (rc == SUFR_HIP_E_HIP) sufr_hip_set_error_(ctx0, "stitching a windowed shard failed"); else sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[r])); release(); return rc; }
-    }
-    // the file: header and name table, the normalised text from the host, every shard's slices from its device
-    const SufrLayout L = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, width, total, a->has_max_query_len, a->max_query_len,
-                                     a->seed_mask, sd.start_positions, sd.num_sequences, (const char* const*)sd.sequence_names);
+    // ---- the file: header, name table, and the normalised text from the host (counting the suffixes on the way) ----
     struct stat ost;
     const int lrc = lstat(outfile.c_str(), &ost);
     const bool in_place = lrc == 0 ? !(S_ISREG(ost.st_mode) && ost.st_nlink == 1) : errno != ENOENT;      // (see sufr_hip_create_from_sequence_multi)
     const std::string partial = in_place ? outfile : outfile + ".partial";
     int fd = ::open(partial.c_str(), O_WRONLY | O_CREAT | O_TRUNC, lrc == 0 && !in_place ? (ost.st_mode & 07777) : 0644);
-    if (fd < 0) { sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str()); release(); return SUFR_HIP_E_IO; }
-    bool ok = pwrite_all(fd, L.head.data(), L.head.size(), 0) && pwrite_all(fd, L.tail.data(), L.tail.size(), L.tail_pos);
+    if (fd < 0) { sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str()); return SUFR_HIP_E_IO; }
+    auto fail = [&](int rc, const char* msg) -> int {
+        if (fd >= 0) (void)close(fd);
+        if (!in_place) (void)unlink(partial.c_str());
+        release();
+        if (msg) sufr_hip_set_error_(ctx0, msg);
+        return rc;
+    };
+    std::atomic<uint64_t> eligible{0};
     {
+        // (the text's place does not depend on the suffix count -- but on the index width: the sequence starts before it are T-wide)
+        const uint64_t text_pos = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, width, 0, a->has_max_query_len, a->max_query_len,
+                                              a->seed_mask, sd.start_positions, sd.num_sequences, (const char* const*)sd.sequence_names).text_pos;
         const uint64_t PIECE = (uint64_t)32 << 20;
-        std::vector<uint8_t> buf(PIECE);
-        for (uint64_t o = 0; ok && o < n; o += PIECE) {
-            const uint64_t len = n - o < PIECE ? n - o : PIECE;
-            (void)sufr_hip_normalize(sd.seq + o, buf.data(), len, a->ignore_softmask);
-            ok = pwrite_all(fd, buf.data(), len, L.text_pos + o);
+        const uint64_t npieces = (n + PIECE - 1) / PIECE;
+        std::atomic<uint64_t> next{0};
+        std::atomic<int> bad{0};
+        unsigned W = host_threads(8);
+        if (W > npieces) W = (unsigned)npieces;
+        const bool every = !a->is_dna || a->allow_ambiguity;
+        std::vector<std::thread> th;
+        for (unsigned w = 0; w < W; w++)
+            th.emplace_back([&]() {
+                std::vector<uint8_t> buf(PIECE);
+                uint64_t mine = 0;
+                for (uint64_t i; !bad && (i = next.fetch_add(1)) < npieces;) {
+                    const uint64_t o = i * PIECE, len = n - o < PIECE ? n - o : PIECE;
+                    (void)sufr_hip_normalize(sd.seq + o, buf.data(), len, a->ignore_softmask);
+                    if (every) mine += len;
+                    else for (uint64_t k = 0; k < len; k++) { const uint8_t c = buf[k]; mine += (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T') | (c == '$'); }
+                    if (!pwrite_all(fd, buf.data(), len, text_pos + o)) bad = 1;
+                }
+                eligible += mine;
+            });
+        for (auto& t : th) t.join();
+        if (bad) return fail(SUFR_HIP_E_IO, (outfile + ": write failed").c_str());
+    }
+    const uint64_t total = eligible.load();
+    const SufrLayout L = sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, n, width, total, a->has_max_query_len, a->max_query_len,
+                                     a->seed_mask, sd.start_positions, sd.num_sequences, (const char* const*)sd.sequence_names);
+    if (!pwrite_all(fd, L.head.data(), L.head.size(), 0) || !pwrite_all(fd, L.tail.data(), L.tail.size(), L.tail_pos))
+        return fail(SUFR_HIP_E_IO, (outfile + ": write failed").c_str());
+    // ---- the text, once per context ----
+    {
+        std::vector<std::thread> th;
+        for (int c = 0; c < n_ctx; c++)
+            th.emplace_back([&, c]() {
+                Dev& x = dv[c];
+                memset(&x.st, 0, sizeof x.st);
+                x.device = sufr_hip_ctx_device_(ctxs[c]);
+                if (hipSetDevice(x.device) != hipSuccess || hipMalloc(&x.d_text, n + 64) != hipSuccess ||
+                    hipMemcpy(x.d_text, sd.seq, n, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMalloc(&x.d_bounds, (size_t)K * 24) != hipSuccess) {
+                    sufr_hip_set_error_(ctxs[c], "out of device memory (text of a windowed shard)"); x.rc = SUFR_HIP_E_NOMEM;
+                }
+            });
+        for (auto& t : th) t.join();
+        for (int c = 0; c < n_ctx; c++)
+            if (dv[c].rc) { if (c) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[c])); return fail(dv[c].rc, nullptr); }
+    }
+    // ---- the shards, in rounds of n_ctx ----
+    std::vector<uint64_t> bounds((size_t)K * 3, 0);            // {first suffix, last suffix, count} of every shard built so far
+    uint64_t off = 0;
+    double t_sort = 0.0;
+    for (uint32_t r0 = 0; r0 < K; r0 += (uint32_t)n_ctx) {
+        const int live = (int)(K - r0 < (uint32_t)n_ctx ? K - r0 : (uint32_t)n_ctx);
+        const double tb = now_s();
+        std::vector<std::thread> th;
+        for (int c = 0; c < live; c++)
+            th.emplace_back([&, c]() {
+                Dev& x = dv[c];
+                const uint32_t r = r0 + (uint32_t)c;
+                if (hipSetDevice(x.device) != hipSuccess) { x.rc = SUFR_HIP_E_HIP; return; }
+                // a shard holds ~1 / K of the suffixes (quantiles of a sample); one that turns out larger gets its size in a second try
+                uint64_t want = total / K + total / (4 * (uint64_t)K) + ((uint64_t)1 << 20);
+                if (want > total) want = total;
+                if (want < 1) want = 1;
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    if (x.cap < want) {
+                        if (x.d_sa) (void)hipFree(x.d_sa);
+                        if (x.d_lcp) (void)hipFree(x.d_lcp);
+                        x.d_sa = x.d_lcp = nullptr; x.cap = 0;
+                        if (hipMalloc(&x.d_sa, want * (size_t)width + 16) != hipSuccess || hipMalloc(&x.d_lcp, want * (size_t)width + 16) != hipSuccess) {
+                            sufr_hip_set_error_(ctxs[c], "out of device memory (arrays of a windowed shard)"); x.rc = SUFR_HIP_E_NOMEM; return;
+                        }
+                        x.cap = want;
+                    }
+                    sufr_hip_stats one;
+                    memset(&one, 0, sizeof one);
+                    x.s = 0;
+                    x.rc = width == 4
+                        ? sufr_hip_sort_device_u32(ctxs[c], x.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
+                                                   r, K, x.d_sa, x.d_lcp, x.cap, &x.s, &one)
+                        : sufr_hip_sort_device_u64(ctxs[c], x.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed,
+                                                   r, K, x.d_sa, x.d_lcp, x.cap, &x.s, &one);
+                    if (r0 == 0) x.st = one;
+                    else { x.st.ms_total += one.ms_total; x.st.ms_partition += one.ms_partition; x.st.ms_passes += one.ms_passes; x.st.ms_deep += one.ms_deep;
+                           x.st.ms_normalize += one.ms_normalize; x.st.ms_hist_text += one.ms_hist_text; x.st.ms_finish += one.ms_finish;
+                           x.st.deep_records += one.deep_records; x.st.num_suffixes += one.num_suffixes; }
+                    if (x.rc != SUFR_HIP_E_CAPACITY || x.s <= x.cap) break;
+                    want = x.s;                          // (the call reports what it needed)
+                }
+                if (x.rc == 0 && x.s) {
+                    uint64_t f = 0, l = 0;
+                    if (hipMemcpy(&f, x.d_sa, (size_t)width, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(&l, (const uint8_t*)x.d_sa + (x.s - 1) * (size_t)width, (size_t)width, hipMemcpyDeviceToHost) != hipSuccess) {
+                        sufr_hip_set_error_(ctxs[c], "reading a shard's ends failed"); x.rc = SUFR_HIP_E_HIP; return;
+                    }
+                    bounds[3 * (size_t)r] = f; bounds[3 * (size_t)r + 1] = l;     // (little-endian: a 4-byte value lands in the low half)
+                }
+                bounds[3 * (size_t)r + 2] = x.s;
+            });
+        for (auto& t : th) t.join();
+        for (int c = 0; c < live; c++)
+            if (dv[c].rc) { if (c) sufr_hip_set_error_(ctx0, sufr_hip_last_error(ctxs[c])); return fail(dv[c].rc, nullptr); }
+        t_sort += now_s() - tb;
+        // the boundary LCP of every shard of the round but the globally first, under the order of the build (k_lcp_stitch), then
+        // the slices
+        for (int c = 0; c < live; c++) {
+            Dev& x = dv[c];
+            const uint32_t r = r0 + (uint32_t)c;
+            if (!x.s) continue;
+            if (off + x.s > total) return fail(SUFR_HIP_E_HIP, "the shards hold more suffixes than the text has eligible positions (internal error)");
+            if (r > 0) {
+                hipError_t he = hipSetDevice(x.device);
+                if (he == hipSuccess) he = hipMemcpy(x.d_bounds, bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice);
+                if (he != hipSuccess) return fail(SUFR_HIP_E_HIP, (std::string("uploading the shard bounds failed: ") + hipGetErrorString(he)).c_str());
+                const int rc = width == 4 ? sufr_hip_stitch_device_u32(ctxs[c], n, (const uint64_t*)x.d_bounds, r, K, x.d_lcp)
+                                          : sufr_hip_stitch_device_u64(ctxs[c], n, (const uint64_t*)x.d_bounds, r, K, x.d_lcp);
+                if (rc) {
+                    const std::string why = std::string("stitching shard ") + std::to_string(r) + " failed: " + sufr_hip_last_error(ctxs[c]);
+                    return fail(rc, why.c_str());
+                }
+            }
+            std::vector<Section> secs;
+            secs.push_back({x.d_sa, x.s * (uint64_t)width, L.sa_pos + off * (uint64_t)width});
+            secs.push_back({x.d_lcp, x.s * (uint64_t)width, L.lcp_pos + off * (uint64_t)width});
+            const int failed = stream_sections(x.device, fd, secs);
+            if (failed) return fail(failed == 1 ? SUFR_HIP_E_HIP : SUFR_HIP_E_IO, failed == 1 ? "device-to-host copy of the arrays failed" : (outfile + ": write failed").c_str());
+            off += x.s;
         }
     }
-    int failed = 0;
-    for (int r = 0; ok && !failed && r < n_ctx; r++) {
-        if (!sh[r].s) continue;
-        std::vector<Section> secs;
-        secs.push_back({sh[r].d_sa, sh[r].s * (uint64_t)width, L.sa_pos + off[r] * (uint64_t)width});
-        secs.push_back({sh[r].d_lcp, sh[r].s * (uint64_t)width, L.lcp_pos + off[r] * (uint64_t)width});
-        failed = stream_sections(sh[r].device, fd, secs);
-    }
-    if (close(fd) != 0) ok = false;
+    if (off != total)
+        return fail(SUFR_HIP_E_HIP, ("the shards hold " + std::to_string(off) + " suffixes, the text has " + std::to_string(total) + " eligible positions (internal error)").c_str());
+    const int crc = close(fd);
+    fd = -1;
+    if (crc != 0) return fail(SUFR_HIP_E_IO, (outfile + ": write failed").c_str());
     release();
-    if (!ok || failed) {
-        if (!in_place) (void)unlink(partial.c_str());
-        sufr_hip_set_error_(ctx0, failed == 1 ? "device-to-host copy of the arrays failed" : (outfile + ": write failed").c_str());
-        return failed == 1 ? SUFR_HIP_E_HIP : SUFR_HIP_E_IO;
-    }
     if (!in_place && rename(partial.c_str(), outfile.c_str()) != 0) {
         sufr_hip_set_error_(ctx0, (outfile + ": " + strerror(errno)).c_str());
         (void)unlink(partial.c_str());
         return SUFR_HIP_E_IO;
     }
     if (stats)
-        for (int r = 0; r < n_ctx; r++) {
-            stats[r] = sh[r].st;
-            stats[r].host_read_s = 0.0f; stats[r].host_build_s = (float)(t_built - t0); stats[r].host_write_s = (float)(now_s() - t_built);
+        for (int c = 0; c < n_ctx; c++) {
+            stats[c] = dv[c].st;
+            stats[c].host_read_s = 0.0f; stats[c].host_build_s = (float)t_sort; stats[c].host_write_s = (float)(now_s() - t0 - t_sort);
         }
     return 0;
+}
+
+// How many shards a windowed create takes: the contexts' count, or -- a budget for the arrays set on the first context
+// (sufr_hip_set_array_budget) -- as many as keep one shard's SA + LCP within it.  Without a budget the count doubles while a
+// build runs out of device memory (up to 64 shards per context): nothing has to be estimated about the windows' workspace.
+static int create_wide_auto(sufr_hip_ctx* const* ctxs, int n_ctx, uint32_t K0, const sufr_sequence_data& sd, const sufr_create_args* a,
+                            const std::string& outfile, sufr_hip_stats* stats)
+{
+    const uint64_t n = sd.seq_len;
+    const uint64_t budget = sufr_hip_array_budget_(ctxs[0]);
+    uint32_t K = K0 < (uint32_t)n_ctx ? (uint32_t)n_ctx : K0;
+    if (budget) {
+        const uint64_t bytes = 2 * n * (uint64_t)(n < 0xFFFFFFFFull ? 4 : 8);      // (an upper bound: every position a suffix)
+        uint64_t k = (bytes + budget - 1) / budget;
+        if (k > 4096) k = 4096;
+        if (k > K) K = (uint32_t)k;
+    }
+    const bool say = getenv("SUFR_HIP_DEBUG") != nullptr;
+    for (;;) {
+        const double t0 = now_s();
+        const int rc = create_wide_sharded(ctxs, n_ctx, K, sd, a, outfile, stats);
+        if (say) fprintf(stderr, "[sufr_hip] windowed create: %u shard%s over %d context%s (array budget %llu): rc %d in %.2f s\n", K, K == 1 ? "" : "s", n_ctx,
+                         n_ctx == 1 ? "" : "s", (unsigned long long)budget, rc, now_s() - t0);
+        if (rc != SUFR_HIP_E_NOMEM || K >= 64u * (uint32_t)n_ctx) return rc;
+        K *= 2;
+    }
 }
 
 // One process, several GPUs: shard r of n_ctx is built on ctxs[r] (a thread per context), then every context
@@ -920,7 +1018,7 @@ int sufr_hip_create_from_sequence_multi(sufr_hip_ctx* const* ctxs, int n_ctx, co
         if (n_ctx == 1 || !all_wide || a->seed_mask || (a->has_max_query_len && a->max_query_len < 8))
             return sufr_hip_create_from_sequence(ctx0, sdp, a, path_out, path_out_len, stats);
         if (a->has_max_query_len && a->seed_mask) { sufr_hip_set_error_(ctx0, "Cannot use max_query_len and seed_mask together"); return SUFR_HIP_E_CONFLICT; }
-        return create_wide_multi(ctxs, n_ctx, sd, a, outfile, stats);
+        return create_wide_auto(ctxs, n_ctx, (uint32_t)n_ctx, sd, a, outfile, stats);
     }
     if (a->has_max_query_len && a->max_query_len < 8) n_ctx = 1;   // (a cap shorter than a first digit ties suffixes across shards)
     if (a->has_max_query_len && a->seed_mask) {            // clap's conflicts_with; builder check 163-165 (before the file is touched)
@@ -1059,11 +1157,22 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* s
     }
     const uint64_t n = sd.seq_len;
     const int width = n < 0xFFFFFFFFull ? 4 : 8;
-    std::vector<uint8_t> norm(n);
+    // Out of core: with a budget for the arrays (sufr_hip_set_array_budget), or when the whole arrays do not fit
+    // the device or the host beside the windows' workspace, the build runs shard after shard and every shard's slice leaves
+    // for the file before the next one is built (create_wide_sharded).  Seed masks and caps below 8 symbols are not sharded.
+    const bool can_shard = !a->seed_mask && !(a->has_max_query_len && a->max_query_len < 8);
+    if (can_shard && sufr_hip_array_budget_(ctx)) return create_wide_auto(&ctx, 1, 1, sd, a, outfile, stats);
+    std::vector<uint8_t> norm;
+    void *sa = nullptr, *lcp = nullptr;
+    try { norm.resize(n); } catch (const std::bad_alloc&) { norm.clear(); }
+    if (norm.size() == n) { sa = malloc((size_t)n * (size_t)width + 8); lcp = malloc((size_t)n * (size_t)width + 8); }
+    if (!sa || !lcp) {
+        free(sa); free(lcp);
+        if (can_shard) return create_wide_auto(&ctx, 1, 2, sd, a, outfile, stats);
+        sufr_hip_set_error_(ctx, "out of host memory (arrays of a windowed build)");
+        return SUFR_HIP_E_NOMEM;
+    }
     uint64_t s = 0;
-    void* sa = malloc((size_t)n * (size_t)width + 8);
-    void* lcp = malloc((size_t)n * (size_t)width + 8);
-    if (!sa || !lcp) { free(sa); free(lcp); return SUFR_HIP_E_NOMEM; }
     const double t_build = now_s();
     int rc = width == 4
         ? sufr_hip_build_u32(ctx, sd.seq, n, build_flags(a), a->has_max_query_len ? a->max_query_len : 0, a->seed_mask,
@@ -1071,6 +1180,12 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx* ctx, const sufr_sequence_data* s
         : sufr_hip_build_u64(ctx, sd.seq, n, build_flags(a), a->has_max_query_len ? a->max_query_len : 0, a->seed_mask,
                              a->num_partitions, a->random_seed, norm.data(), (uint64_t*)sa, (uint64_t*)lcp, n, &s, stats);
     if (stats) stats->host_build_s = (float)(now_s() - t_build);
+    if (rc == SUFR_HIP_E_NOMEM && can_shard) {                      // the whole arrays do not fit the device: shard after shard
+        if (getenv("SUFR_HIP_DEBUG")) fprintf(stderr, "[sufr_hip] windowed create: the whole arrays do not fit (%s): building shard after shard\n", sufr_hip_last_error(ctx));
+        free(sa); free(lcp);
+        std::vector<uint8_t>().swap(norm);
+        return create_wide_auto(&ctx, 1, 2, sd, a, outfile, stats);
+    }
     if (rc == 0) {
         rc = sufr_write_file(outfile.c_str(), a->is_dna, a->allow_ambiguity, a->ignore_softmask, norm.data(), n,
                              width, sa, lcp, s, a->has_max_query_len, a->max_query_len, a->seed_mask,

@@ -480,3 +480,80 @@ def test_cli_windowed_create_over_contexts_equals_the_one_context_file(tmp_path)
             assert r.returncode == 0, r.stderr
             files.append(out.read_bytes())
         assert files[0] == files[1] == files[2]
+
+
+# ---- out of core: a windowed create whose arrays leave for the file shard after shard (sufr_hip_set_array_budget) ----
+
+@pytest.mark.parametrize("name", ["long_dna_sequence.sufr", "long_dna_sequence_allow_ambiguity.sufr", "uniprot.sufr", "2.sufr", "1.sufr"])
+@pytest.mark.parametrize("devs", ["0", "0,0"])
+def test_cli_out_of_core_create_writes_the_golden_file(tmp_path, name, devs):
+    """`sufr create --window W --array-budget B`: the arrays never exist as a whole -- ceil(2 n width / B) shards are built one
+    after another (two contexts: in rounds of two) and each slice is streamed to its place in the file before the next shard is
+    built.  The reference's golden files byte for byte, with a budget of a seventh of the arrays."""
+    case = GOLDEN_CASES[name]
+    out = tmp_path / name
+    golden = (GOLDEN / "expected" / name).read_bytes()
+    n = len(golden)
+    args = [str(sufr_amd.CLI_PATH), "--devices", devs, "create", str(GOLDEN / "inputs" / case["fa"]), "-o", str(out), "-n", "16", "-r", "42",
+            "--window", str(max(16, n // 40)), "--margin", "48", "--array-budget", str(max(64, n // 9 * 8 // 7))]
+    if case.get("is_dna"):
+        args.append("-d")
+    if case.get("allow_ambiguity"):
+        args.append("-a")
+    if case.get("ignore_softmask"):
+        args.append("-i")
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == golden
+    assert not (tmp_path / (name + ".partial")).exists()
+
+
+def test_out_of_core_create_equals_the_whole_array_create(tmp_path):
+    """6 Mb of DNA with soft-masked stretches, N runs and repeats over window ends, in windows of 1.1 Mb: budgets that make 1, 3, 8
+    and 23 shards write the file the whole-array path writes -- plain, --allow-ambiguity and -m 25; a seed mask keeps the
+    whole-array path whatever the budget says"""
+    rng = np.random.default_rng(77)
+    t = repeat_text(6_000_000, 31, 4000, 60)
+    body = t[:-1].copy()
+    for _ in range(40):
+        p = int(rng.integers(0, body.size - 3000)); body[p : p + int(rng.integers(5, 3000))] = ord("N")
+    low = body.copy()
+    for _ in range(60):
+        p = int(rng.integers(0, low.size - 5000)); q = p + int(rng.integers(50, 5000)); low[p:q] |= 0x20
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b">a\n" + low[: low.size // 2].tobytes() + b"\n>b\n" + low[low.size // 2 :].tobytes() + b"\n")
+    n = low.size + 2
+    for extra in (["-d"], ["-d", "-a"], ["-d", "-m", "25"], ["-d", "-i"], ["-d", "-s", "1101"]):
+        ref = tmp_path / "ref.sufr"
+        r = subprocess.run([str(sufr_amd.CLI_PATH), "create", str(fa), "-o", str(ref), "--window", "1100000", "--margin", "5000"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        want = ref.read_bytes()
+        for shards, devs in ((1, "0"), (3, "0"), (8, "0,0,0"), (23, "0,0")):
+            out = tmp_path / "o.sufr"
+            r = subprocess.run([str(sufr_amd.CLI_PATH), "--devices", devs, "create", str(fa), "-o", str(out), "--window", "1100000", "--margin", "5000",
+                                "--array-budget", str(2 * n * 4 // shards + 8)] + extra, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert out.read_bytes() == want, (extra, shards, devs)
+
+
+def test_out_of_core_create_through_the_c_abi(tmp_path):
+    """sufr_hip_set_array_budget + sufr_hip_create_file on one context: the same file; budget 0 restores the whole-array path"""
+    import ctypes as C
+    from sufr_amd import _lib, cli
+    t = repeat_text(300_000, 5, 700, 30)
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b">r\n" + t[:-1].tobytes() + b"\n")
+    files = []
+    ctx = _lib.Context(0)
+    ctx.set_window(50_000, 2_000)
+    for budget in (0, 300_000, 0):
+        ctx.set_array_budget(budget)
+        out = tmp_path / f"o{len(files)}.sufr"
+        a = cli.create_args(str(fa), str(out), is_dna=True)
+        path = C.create_string_buffer(4096)
+        st = _lib.Stats()
+        ctx.check(_lib.lib().sufr_hip_create_file(ctx.handle, C.byref(a), path, len(path), C.byref(st)))
+        files.append(out.read_bytes())
+    ctx.close()
+    assert files[0] == files[1] == files[2]
