@@ -1695,6 +1695,7 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
     bool act1 = small1 && !(h1 && nx1 == 64 + ln + 1);
     uint32_t gid0 = act0 ? (uint32_t)g0 : (0x10000u | (uint32_t)ln);
     uint32_t gid1 = act1 ? (uint32_t)g1 : (0x10000u | (uint32_t)(64 + ln));
+    uint32_t ge0 = act0 ? (uint32_t)nx0 : 0u, ge1 = act1 ? (uint32_t)nx1 : 0u;      // end of the slot's group (active slots)
 
     int ktype = DEEP ? 1 : 0;                 // keys currently held: 0 plain packed characters, 1 run keys, 2 walk keys
     uint32_t extra0 = 0, extra1 = 0;          // characters a capped pair walk has matched beyond the key
@@ -1707,24 +1708,28 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         ph__[5] += 1000;                      // (rounds, in thousands of a 'cycle')
 #endif
         // ---- rank every active record inside its group (counting sort through LDS) ----------------
-        sk[ln] = k0; sk[64 + ln] = k1; sg[ln] = gid0; sg[64 + ln] = gid1;
+        // The group's slots are [gid, ge): the bounds are known from the head / tie masks, so the loop reads four keys per trip
+        // with nothing between the loads (round 5: the loop used to find the group's end by reading a slot's group id before its
+        // key -- two dependent LDS round trips per member, 44 % of the kernel's time on groups of ~27).
+        sk[ln] = k0; sk[64 + ln] = k1;
         uint32_t np0 = (uint32_t)ln, np1 = (uint32_t)(64 + ln);
-        if (act0) {
-            uint32_t cnt = 0;
-            for (uint32_t t = gid0; t < 128u && sg[t] == gid0; t++) {
-                uint64_t kt = sk[t];
-                cnt += (kt < k0 || (kt == k0 && t < (uint32_t)ln)) ? 1u : 0u;
+        auto rank_in = [&](uint64_t kme, uint32_t me, uint32_t g, uint32_t e) -> uint32_t {
+            uint32_t cnt = 0, t = g;
+            for (; t + 4u <= e; t += 4u) {
+                const uint64_t a = sk[t], b = sk[t + 1], c = sk[t + 2], d = sk[t + 3];
+                cnt += (a < kme || (a == kme && t < me)) ? 1u : 0u;
+                cnt += (b < kme || (b == kme && t + 1u < me)) ? 1u : 0u;
+                cnt += (c < kme || (c == kme && t + 2u < me)) ? 1u : 0u;
+                cnt += (d < kme || (d == kme && t + 3u < me)) ? 1u : 0u;
             }
-            np0 = gid0 + cnt;
-        }
-        if (act1) {
-            uint32_t cnt = 0;
-            for (uint32_t t = gid1; t < 128u && sg[t] == gid1; t++) {
-                uint64_t kt = sk[t];
-                cnt += (kt < k1 || (kt == k1 && t < (uint32_t)(64 + ln))) ? 1u : 0u;
+            for (; t < e; t++) {
+                const uint64_t a = sk[t];
+                cnt += (a < kme || (a == kme && t < me)) ? 1u : 0u;
             }
-            np1 = gid1 + cnt;
-        }
+            return cnt;
+        };
+        if (act0) np0 = gid0 + rank_in(k0, (uint32_t)ln, gid0, ge0);
+        if (act1) np1 = gid1 + rank_in(k1, (uint32_t)(64 + ln), gid1, ge1);
         // every lane has finished reading (one wave, in-order LDS); move the records
         if (act0) { sk[np0] = k0; si[np0] = i0; }
         if (act1) { sk[np1] = k1; si[np1] = i1; }
@@ -1753,6 +1758,8 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         act1 = act1 && (tie1 || s1n);
         gid0 = act0 ? (uint32_t)ng0 : (0x10000u | (uint32_t)ln);
         gid1 = act1 ? (uint32_t)ng1 : (0x10000u | (uint32_t)(64 + ln));
+        ge0 = (uint32_t)mask_next_set(~T0, ~T1, ln, 128);                  // the next slot that does not tie with its predecessor
+        ge1 = (uint32_t)mask_next_set(~T0, ~T1, 64 + ln, 128);
         lt0 = tie0; lt1 = tie1;
         if (TIES_OUT) break;                  // tie runs go to the dense tie level (k_build_ties)
         SUFR_STAMP(ph__, 1)
