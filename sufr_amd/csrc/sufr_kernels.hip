@@ -1844,13 +1844,18 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
             }
             ktype = 2;
         } else {
-            if (act0) {
-                dd0 += advance(k0) + extra0; extra0 = 0;
-                k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u, kp.packed);
-            }
-            if (act1) {
-                dd1 += advance(k1) + extra1; extra1 = 0;
-                k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u, kp.packed);
+            if (act0) { dd0 += advance(k0) + extra0; extra0 = 0; }
+            if (act1) { dd1 += advance(k1) + extra1; extra1 = 0; }
+            if (kp.packed) {
+                // both slots' sectors are asked for before either is waited for: one random-read latency per round, not two
+                PackedPair f0 = {0ull, 0ull}, f1 = {0ull, 0ull};
+                if (act0) f0 = packed_fetch16(kp.packed, kp.b, (uint64_t)i0 + dd0 - 1u);
+                if (act1) f1 = packed_fetch16(kp.packed, kp.b, (uint64_t)i1 + dd1 - 1u);
+                if (act0) k0 = make_run_key_packed(n, R, kp.b, (uint64_t)i0 + dd0, kp.packed, f0);
+                if (act1) k1 = make_run_key_packed(n, R, kp.b, (uint64_t)i1 + dd1, kp.packed, f1);
+            } else {
+                if (act0) k0 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i0 + dd0, 1u, nullptr);
+                if (act1) k1 = make_run_key(text, n, R, s_lut, kp.b, (uint64_t)i1 + dd1, 1u, nullptr);
             }
             ktype = 1;
         }

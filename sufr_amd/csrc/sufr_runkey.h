@@ -187,6 +187,57 @@ SUFR_HD uint32_t leading_equal_codes(uint64_t v, uint32_t code, int bits)
     return x ? div_by_bits((uint32_t)__builtin_clzll(x << spare), bits) : K;
 }
 
+// The run key of position q from the packed code stream alone (period 1), in two steps so that a caller with several
+// positions in hand can issue all their first reads before it waits for any (k_finish re-keys two slots per lane: one
+// random-sector latency per round instead of two): packed_fetch16(q - 1) = the 16 bytes that hold the codes at q - 1, q and
+// the ~20 after them; make_run_key_packed() turns them into the key.  Codes are the ranks of the bytes: equal codes <=> equal
+// bytes, code order = byte order.  Only a run (text[q] == text[q - 1]) that does not end inside the codes in hand costs more:
+// the run-end table, then the same read behind the run.
+struct PackedPair { uint64_t hi, lo; };
+SUFR_HD PackedPair packed_fetch16(const uint8_t* __restrict__ packed, int bits, uint64_t p)
+{
+    const uint8_t* pp = packed + ((p * (uint64_t)bits) >> 3);
+    PackedPair w;
+    w.hi = __builtin_bswap64(load_u64_unaligned(pp)); w.lo = __builtin_bswap64(load_u64_unaligned(pp + 8));
+    return w;
+}
+// 64 bits of codes from p and from p + 1 on, out of the 16 bytes fetched for p
+SUFR_HD void packed_codes_at(PackedPair w, int bits, uint64_t p, uint64_t& from_p, uint64_t& from_next)
+{
+    const uint32_t s0 = (uint32_t)((p * (uint64_t)bits) & 7u), s1 = s0 + (uint32_t)bits;        // s1 <= 11
+    from_p = s0 ? ((w.hi << s0) | (w.lo >> (64 - s0))) : w.hi;
+    from_next = (w.hi << s1) | (w.lo >> (64 - s1));
+}
+SUFR_HD uint64_t make_run_key_packed(uint64_t n, RunTable rt, int bits, uint64_t q, const uint8_t* __restrict__ packed,
+                                     PackedPair first /* packed_fetch16(packed, bits, q - 1) */)
+{
+    uint32_t rem = 0;
+    uint64_t vprev, vq;
+    packed_codes_at(first, bits, q - 1, vprev, vq);
+    uint32_t cprev = (uint32_t)(vprev >> (64 - bits)), cq = (uint32_t)(vq >> (64 - bits));
+    if (q < n && cq == cprev) {
+        // a run that ends inside the ~20 codes in hand (every fourth suffix of a DNA text continues its last character;
+        // almost all such runs are a few characters long) needs no look at the run-end table: another random sector
+        const uint32_t eq = leading_equal_codes(vq, cprev, bits);
+        rem = eq < div_by_bits(64u, bits) ? eq : run_len_at(q, rt);
+        packed_codes_at(packed_fetch16(packed, bits, q + rem - 1), bits, q + rem - 1, vprev, vq);
+        cprev = (uint32_t)(vprev >> (64 - bits)); cq = (uint32_t)(vq >> (64 - bits));
+    }
+    const uint64_t after = q + rem;
+    const uint32_t cls = (after < n && cq > cprev) ? 1u : 0u;
+    const uint32_t v = rem + 1u;
+    const int L = 31 - __builtin_clz(v);
+    const int glen = 2 * L + 1;
+    uint64_t g = (((1ull << L) - 1ull) << (L + 1)) | (uint64_t)(v & ((1u << L) - 1u));
+    if (cls) g = ~g & ((1ull << glen) - 1ull);
+    const int tokbits = 1 + glen;
+    const uint64_t key = ((uint64_t)cls << 63) | (g << (63 - glen));
+    const int shift = 64 - tokbits;
+    const int nch = (int)div_by_bits((uint32_t)shift, bits);
+    const int spare = shift - nch * bits;                                        // unused low bits
+    return key | ((vq >> tokbits) & (~0ull << spare));                           // vq: the codes from `after` on
+}
+
 // pi = period assumed for the group (1 = plain runs, served by the run-end table).  Any pi <= the length of
 // the group's common prefix gives a valid order: all members agree on the pi bytes before q, hence on the
 // periodic extension up to the shorter of their two break points, and at the break the suffix whose text
@@ -202,34 +253,8 @@ SUFR_HD uint64_t make_run_key(const uint8_t* __restrict__ text, uint64_t n,
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     uint64_t after;
     uint32_t x, c;
-    if (packed && pi == 1) {
-        // Everything from the packed code stream (codes are the ranks of the bytes: equal codes <=> equal bytes, code
-        // order = byte order): the codes at q - 1, q and the ~20 after them are ONE unaligned 16-byte read -- one
-        // 64-byte sector of a random suffix instead of one in the byte text plus one in the packed stream.  Only a
-        // run (text[q] == text[q - 1]) costs more: the run-end table, then the same read behind the run.
-        auto codes_at = [&](uint64_t p, uint64_t& from_p, uint64_t& from_next) {     // 64 bits of codes from p / p + 1 on
-            const uint64_t o = p * (uint64_t)bits;
-            const uint8_t* pp = packed + (o >> 3);
-            const uint32_t s0 = (uint32_t)(o & 7u), s1 = s0 + (uint32_t)bits;        // s1 <= 11
-            const uint64_t hi = __builtin_bswap64(load_u64_unaligned(pp)), lo = __builtin_bswap64(load_u64_unaligned(pp + 8));
-            from_p = s0 ? ((hi << s0) | (lo >> (64 - s0))) : hi;
-            from_next = (hi << s1) | (lo >> (64 - s1));
-        };
-        uint64_t vprev, vq;
-        codes_at(q - 1, vprev, vq);
-        uint32_t cprev = (uint32_t)(vprev >> (64 - bits)), cq = (uint32_t)(vq >> (64 - bits));
-        if (q < n && cq == cprev) {
-            // a run that ends inside the ~20 codes in hand (every fourth suffix of a DNA text continues its last character;
-            // almost all such runs are a few characters long) needs no look at the run-end table: another random sector
-            const uint32_t eq = leading_equal_codes(vq, cprev, bits);
-            rem = eq < div_by_bits(64u, bits) ? eq : run_len_at(q, rt);
-            codes_at(q + rem - 1, vprev, vq);
-            cprev = (uint32_t)(vprev >> (64 - bits)); cq = (uint32_t)(vq >> (64 - bits));
-        }
-        after = q + rem;
-        x = cq; c = cprev;
-        pw = vq;                                           // codes from `after` on (ps = 0)
-    } else {
+    if (packed && pi == 1) return make_run_key_packed(n, rt, bits, q, packed, packed_fetch16(packed, bits, q - 1));
+    {
         if (pi == 1) {
             const uint32_t cprev = text[q - 1], cq = text[q];
             if (q < n && cq == cprev) rem = run_len_at(q, rt);
