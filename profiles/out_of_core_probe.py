@@ -92,6 +92,12 @@ def main():
     s = f.len_suffixes
     assert f.text_len == n and f.index_width == (8 if n >= 0xFFFFFFFF else 4)
     dt = torch.int64 if f.index_width == 8 else torch.int32
+    need = 2 * s * f.index_width + n + (8 << 30)
+    for _ in range(120):                                       # (the CLI leaves through _exit: the driver hands its HBM back a little later)
+        if torch.cuda.mem_get_info()[0] >= need:
+            break
+        time.sleep(1.0)
+    print(f"free HBM after the create: {torch.cuda.mem_get_info()[0] / 1e9:.0f} GB (the check needs {need / 1e9:.0f})", flush=True)
     t0 = time.time()
     d_sa = torch.empty(s, dtype=dt, device="cuda"); d_lcp = torch.empty(s, dtype=dt, device="cuda")
     fsa, flcp = f.suffix_array, f.lcp
