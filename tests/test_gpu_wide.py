@@ -557,3 +557,23 @@ def test_out_of_core_create_through_the_c_abi(tmp_path):
         files.append(out.read_bytes())
     ctx.close()
     assert files[0] == files[1] == files[2]
+
+
+def test_skewed_shard_grows_its_window_rank_arrays():
+    """A shard's window ranks get a shard's share of memory (n / K x 1.5 + 2^20 entries) and grow, contents kept, when a window needs
+    more.  5.2 M 'A' followed by random DNA, five shards in windows of 1.3 M: every suffix of the run starts with the same 8 bytes,
+    so ONE shard holds 5.2 M suffixes against room for 2.8 M -- its arrays grow twice while windows are being filtered.  The shards
+    concatenate to the one-window build of the same text."""
+    rng = np.random.default_rng(5)
+    n = 6_000_000
+    t = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    t[100_000:5_300_000] = ord("A")
+    t[-1] = ord("$")
+    x = torch.from_numpy(t).cuda()
+    db = sufr_amd.DeviceBuilder(0)
+    one_sa, one_lcp = db.sort(x, is_dna=True)
+    one_sa = one_sa.cpu().numpy().view(np.uint32).astype(np.uint64); one_lcp = one_lcp.cpu().numpy().view(np.uint32).astype(np.uint64)
+    db.close()
+    sa, lcp, sizes, _ = sharded_windowed(x, n, 5, 1_300_000, 4096, 8, is_dna=True)
+    assert max(sizes) > 5_000_000 and sum(sizes) == one_sa.size
+    assert np.array_equal(sa, one_sa) and np.array_equal(lcp, one_lcp)
