@@ -1767,15 +1767,19 @@ k_finish(const uint64_t* __restrict__ keys, const uint32_t* idxs,
         // characters per step, instead of being re-keyed ~20 characters per round: an exact duplicate of 100 kb is
         // 10^5 such pairs with common prefixes of up to 10^5 characters (find_lcp's byte walk, sufr_builder.rs:
         // 319-329, as a word walk).  The head lane of a pair does the walk; results travel through the LDS.
-        {
-            auto tbit = [&](int t) -> bool {
-                return t < 64 ? ((T0 >> t) & 1ull) != 0 : (t < 128 ? ((T1 >> (t - 64)) & 1ull) != 0 : false);
-            };
-            const bool ph0 = act0 && !tie0 && tbit(ln + 1) && !tbit(ln + 2);
-            const bool ph1 = act1 && !tie1 && tbit(64 + ln + 1) && !tbit(64 + ln + 2);
-            const bool ps0 = act0 && tie0 && !tbit(ln + 1) && ln >= 1 && !tbit(ln - 1);
-            const bool ps1 = act1 && tie1 && !tbit(64 + ln + 1) && !tbit(64 + ln - 1);
-            if (!(popts & 1u) && __ballot(ph0 || ph1) != 0ull) {
+        // (the pair heads / seconds as 128-bit masks out of the tie masks -- wave-uniform words, scalar shifts -- so that a round
+        // without pairs leaves here on a scalar test: round 5; each lane used to test five bits of T around its slots first)
+        const uint64_t TN0 = (T0 >> 1) | (T1 << 63), TN1 = T1 >> 1;                 // tie of the slot after
+        const uint64_t TNN0 = (T0 >> 2) | (T1 << 62), TNN1 = T1 >> 2;               // ... two after
+        const uint64_t TP0 = T0 << 1, TP1 = (T1 << 1) | (T0 >> 63);                 // ... before
+        const uint64_t PH0 = ~T0 & TN0 & ~TNN0, PH1 = ~T1 & TN1 & ~TNN1;            // heads a group of exactly two
+        const uint64_t PS0 = T0 & ~TN0 & ~TP0, PS1 = T1 & ~TN1 & ~TP1;              // its second member
+        if (!(popts & 1u) && (PH0 | PH1) != 0ull) {
+            const bool ph0 = act0 && ((PH0 >> ln) & 1ull) != 0ull;
+            const bool ph1 = act1 && ((PH1 >> ln) & 1ull) != 0ull;
+            const bool ps0 = act0 && ((PS0 >> ln) & 1ull) != 0ull;
+            const bool ps1 = act1 && ((PS1 >> ln) & 1ull) != 0ull;
+            if (__ballot(ph0 || ph1) != 0ull) {
                 auto walk = [&](uint32_t slot, uint32_t mine, uint32_t dnew) {
                     const uint32_t other = si[slot + 1];
                     const uint64_t a = (uint64_t)mine + dnew, b = (uint64_t)other + dnew;
