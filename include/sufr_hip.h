@@ -123,8 +123,8 @@ uint64_t sufr_hip_window_repairs(const sufr_hip_ctx *ctx);
  * partitions sorted one at a time out of temporary files, sufr_builder.rs:495-598 + write() 875-906): `bytes` = device memory
  * the suffix and LCP arrays may occupy at once.  The build then runs in ceil(2 * n * width / bytes) shards (ranges of the first
  * 8 bytes), one after another on every context, and each shard's slice is streamed to its place in the file before the next is
- * built -- the whole arrays are never resident, on the device or the host.  0 (the default): no limit set; a create whose
- * arrays do not fit beside the windows' workspace falls back to 2, 4, 8 ... shards by itself.  The price is one windowed
+ * built -- the whole arrays are never resident, on the device or the host.  0 (the default): no limit set; a create starts
+ * with one shard per context and goes to 2, 4, 8 ... times as many while a build runs out of device memory.  The price is one windowed
  * sort of the text per shard.  Seed-mask builds and max_query_len < 8 are not sharded (they keep the whole-array path). */
 int  sufr_hip_set_array_budget(sufr_hip_ctx *ctx, uint64_t bytes);
 
