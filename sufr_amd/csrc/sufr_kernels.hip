@@ -1502,18 +1502,24 @@ __device__ __forceinline__ uint64_t walk_lcp_packed(const uint8_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 3; u++) { wa[u] = __builtin_bswap64(load_u64_unaligned(pa + 8 * u)); wb[u] = __builtin_bswap64(load_u64_unaligned(pb + 8 * u)); }
         const uint32_t sa = (uint32_t)(oa & 7u), sb = (uint32_t)(ob & 7u);
+        // two words of K codes, then what the 24 bytes still hold behind them: 192 - 7 - 2 K bits >= K3 whole codes (round 5: the
+        // third piece was read and not looked at; 42 -> 61 symbols per round trip for 3-bit codes)
+        const uint32_t K3 = div_by_bits(192u - 7u - 2u * K * (uint32_t)bits, bits);
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t qa = sa + (uint32_t)j * K * (uint32_t)bits, qb = sb + (uint32_t)j * K * (uint32_t)bits;   // < 8 + 64
+        for (int j = 0; j < 3; j++) {
+            const uint32_t qa = sa + (uint32_t)j * K * (uint32_t)bits, qb = sb + (uint32_t)j * K * (uint32_t)bits;   // < 8 + 128
             const uint32_t ra = qa & 63u, rb = qb & 63u;
             // (selects, not indexed registers)
-            const uint64_t ha = qa < 64u ? wa[0] : wa[1], la = qa < 64u ? wa[1] : wa[2];
-            const uint64_t hb = qb < 64u ? wb[0] : wb[1], lb = qb < 64u ? wb[1] : wb[2];
+            const uint64_t ha = qa < 64u ? wa[0] : (qa < 128u ? wa[1] : wa[2]), la = qa < 64u ? wa[1] : (qa < 128u ? wa[2] : 0ull);
+            const uint64_t hb = qb < 64u ? wb[0] : (qb < 128u ? wb[1] : wb[2]), lb = qb < 64u ? wb[1] : (qb < 128u ? wb[2] : 0ull);
             const uint64_t va = ra ? ((ha << ra) | (la >> (64u - ra))) : ha;
             const uint64_t vb = rb ? ((hb << rb) | (lb >> (64u - rb))) : hb;
-            const uint64_t x = (va ^ vb) >> spare;
+            const uint32_t Kj = j < 2 ? K : K3;                                   // whole codes compared in this piece
+            const int sparej = 64 - (int)Kj * bits;
+            if (Kj == 0u) break;
+            const uint64_t x = (va ^ vb) >> sparej;
             if (x) {
-                const uint32_t c = div_by_bits((uint32_t)__builtin_clzll(x << spare), bits);
+                const uint32_t c = div_by_bits((uint32_t)__builtin_clzll(x << sparej), bits);
                 k += c;
                 if (k >= lim) return lim;
                 const int sh = 64 - (int)(c + 1u) * bits;
@@ -1521,7 +1527,7 @@ __device__ __forceinline__ uint64_t walk_lcp_packed(const uint8_t* __restrict__ 
                 cb = (uint32_t)(vb >> sh) & ((1u << bits) - 1u);
                 return k;
             }
-            k += K;
+            k += Kj;
             if (k >= lim) return lim;
         }
     }
