@@ -267,6 +267,9 @@ int sufr_hip_create_from_sequence(sufr_hip_ctx *ctx, const sufr_sequence_data *s
  * One process per GPU (torch.distributed / MPI ranks): every rank calls sufr_hip_shard_build, the ranks exchange
  * their sufr_shard_info (24 bytes each: the only collective of the path), rank 0 calls sufr_write_frame, and after
  * a barrier every rank calls sufr_hip_shard_write with the suffix count of the ranks before it.
+ * Texts that take windows too (round 5): the shard of the windowed build -- SA / LCP of the file's index width -- is kept
+ * in device memory of its own, per context, until sufr_hip_shard_write has streamed it (or the context builds again or is
+ * destroyed); seed-mask builds and caps below 8 symbols of such texts return SUFR_HIP_E_UNSUPPORTED for num_shards > 1.
  *
  * Device memory of one shard of N (text of n bytes, s suffixes in all): the text and its packed / bitmap forms
  * (~1.6 n), SA + LCP of the shard (8 s / N, sized from the shard's exact count), two record arrays (24 s / N) and the

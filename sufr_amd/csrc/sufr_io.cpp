@@ -18,6 +18,8 @@
 
 #include <atomic>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -320,7 +322,7 @@ uint32_t build_flags(const sufr_create_args* a)
 
 SufrLayout layout_of(const sufr_sequence_data& sd, const sufr_create_args* a, uint64_t num_suffixes)
 {
-    return sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, sd.seq_len, 4, num_suffixes,
+    return sufr_layout(a->is_dna, a->allow_ambiguity, a->ignore_softmask, sd.seq_len, sd.seq_len < 0xFFFFFFFFull ? 4 : 8 /* suffix_array.rs:461 */, num_suffixes,
                        a->has_max_query_len, a->max_query_len, a->seed_mask, sd.start_positions, sd.num_sequences,
                        (const char* const*)sd.sequence_names);
 }
@@ -723,6 +725,148 @@ int sufr_write_frame(const char* outfile, const sufr_sequence_data* sd, const su
     return 0;
 }
 
+// ---- the one-rank-per-GPU writer for texts that take windows (round 5) -----------------------------------------------
+// sufr_hip_shard_build keeps such a shard outside the context's own build arrays: the raw text, and SA / LCP of the file's
+// index width, in device memory of their own, remembered per context until sufr_hip_shard_write has streamed them (or the
+// context builds again / is destroyed: sufr_io_release_ctx_, called by sufr_hip_destroy).
+namespace {
+struct WideResident { void *d_text = nullptr, *d_sa = nullptr, *d_lcp = nullptr; uint64_t s = 0, n = 0, first = 0; int width = 0, device = 0; };
+std::mutex g_wide_mu;
+std::unordered_map<const sufr_hip_ctx*, WideResident> g_wide;
+void wide_free(WideResident& w)
+{
+    if (hipSetDevice(w.device) == hipSuccess)
+        for (void* q : {w.d_text, w.d_sa, w.d_lcp}) if (q) (void)hipFree(q);
+    w = WideResident();
+}
+}  // namespace
+
+extern "C" void sufr_io_release_ctx_(const sufr_hip_ctx* ctx)
+{
+    WideResident w;
+    {
+        std::lock_guard<std::mutex> g(g_wide_mu);
+        auto it = g_wide.find(ctx);
+        if (it == g_wide.end()) return;
+        w = it->second;
+        g_wide.erase(it);
+    }
+    wide_free(w);
+}
+
+static int wide_shard_build(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const sufr_create_args* a, uint32_t shard_index,
+                            uint32_t num_shards, sufr_shard_info* info, sufr_hip_stats* stats)
+{
+    sufr_io_release_ctx_(ctx);
+    const uint64_t n = sd->seq_len;
+    WideResident w;
+    w.n = n; w.width = n < 0xFFFFFFFFull ? 4 : 8; w.device = sufr_hip_ctx_device_(ctx);
+    const uint32_t flags = build_flags(a);
+    const uint64_t mql = a->has_max_query_len ? a->max_query_len : 0;
+    if (hipSetDevice(w.device) != hipSuccess || hipMalloc(&w.d_text, n + 64) != hipSuccess ||
+        hipMemcpy(w.d_text, sd->seq, n, hipMemcpyHostToDevice) != hipSuccess) {
+        wide_free(w);
+        sufr_hip_set_error_(ctx, "out of device memory (text of a windowed shard)");
+        return SUFR_HIP_E_NOMEM;
+    }
+    uint64_t cap = n / num_shards + n / (4ull * num_shards) + ((uint64_t)1 << 20);
+    int rc = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (cap > n) cap = n;
+        if (hipMalloc(&w.d_sa, cap * (size_t)w.width + 16) != hipSuccess || hipMalloc(&w.d_lcp, cap * (size_t)w.width + 16) != hipSuccess) {
+            wide_free(w);
+            sufr_hip_set_error_(ctx, "out of device memory (arrays of a windowed shard)");
+            return SUFR_HIP_E_NOMEM;
+        }
+        w.s = 0;
+        rc = w.width == 4
+            ? sufr_hip_sort_device_u32(ctx, w.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed, shard_index, num_shards,
+                                       w.d_sa, w.d_lcp, cap, &w.s, stats)
+            : sufr_hip_sort_device_u64(ctx, w.d_text, n, flags, mql, a->seed_mask, a->num_partitions, a->random_seed, shard_index, num_shards,
+                                       w.d_sa, w.d_lcp, cap, &w.s, stats);
+        if (rc != SUFR_HIP_E_CAPACITY || w.s <= cap) break;
+        (void)hipFree(w.d_sa); (void)hipFree(w.d_lcp); w.d_sa = w.d_lcp = nullptr;
+        cap = w.s;                                   // (the call reports what it needed)
+    }
+    if (rc) { wide_free(w); return rc; }
+    info->num_suffixes = w.s;
+    if (w.s) {
+        uint64_t f = 0, l = 0;
+        if (hipMemcpy(&f, w.d_sa, (size_t)w.width, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&l, (const uint8_t*)w.d_sa + (w.s - 1) * (size_t)w.width, (size_t)w.width, hipMemcpyDeviceToHost) != hipSuccess) {
+            wide_free(w);
+            sufr_hip_set_error_(ctx, "reading a shard's ends failed");
+            return SUFR_HIP_E_HIP;
+        }
+        info->first_suffix = w.first = f; info->last_suffix = l;      // (little-endian: a 4-byte value lands in the low half)
+    }
+    std::lock_guard<std::mutex> g(g_wide_mu);
+    g_wide[ctx] = w;
+    return 0;
+}
+
+static int wide_shard_write(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const sufr_create_args* a, const char* outfile,
+                            uint64_t num_suffixes, uint64_t total_suffixes, uint64_t suffix_offset, int has_prev, uint64_t prev_last_suffix,
+                            int write_text)
+{
+    WideResident w;
+    {
+        std::lock_guard<std::mutex> g(g_wide_mu);
+        auto it = g_wide.find(ctx);
+        if (it == g_wide.end() || it->second.n != sd->seq_len || it->second.s != num_suffixes) {
+            sufr_hip_set_error_(ctx, "sufr_hip_shard_write: the context holds no windowed shard of this text (sufr_hip_shard_build first; a write consumes it)");
+            return SUFR_HIP_E_INVALID;
+        }
+        w = it->second;
+        g_wide.erase(it);
+    }
+    struct Free { WideResident& w; ~Free() { wide_free(w); } } guard{w};
+    const uint64_t n = sd->seq_len;
+    int rc = 0;
+    if (has_prev && num_suffixes) {
+        // the boundary LCP under the order of the build (k_lcp_stitch): a two-row table {-, prev.last, 1}, {first, -, s}
+        const uint64_t rows[6] = {0, prev_last_suffix, 1, w.first, 0, w.s};
+        void* d_rows = nullptr;
+        if (hipSetDevice(w.device) != hipSuccess || hipMalloc(&d_rows, sizeof rows) != hipSuccess ||
+            hipMemcpy(d_rows, rows, sizeof rows, hipMemcpyHostToDevice) != hipSuccess) {
+            if (d_rows) (void)hipFree(d_rows);
+            sufr_hip_set_error_(ctx, "uploading the boundary of a windowed shard failed");
+            return SUFR_HIP_E_HIP;
+        }
+        rc = w.width == 4 ? sufr_hip_stitch_device_u32(ctx, n, (const uint64_t*)d_rows, 1, 2, w.d_lcp)
+                          : sufr_hip_stitch_device_u64(ctx, n, (const uint64_t*)d_rows, 1, 2, w.d_lcp);
+        (void)hipFree(d_rows);
+        if (rc) return rc;
+    }
+    const SufrLayout L = layout_of(*sd, a, total_suffixes);
+    int fd = ::open(outfile, O_WRONLY);
+    if (fd < 0) { sufr_hip_set_error_(ctx, (std::string(outfile) + ": " + strerror(errno)).c_str()); return SUFR_HIP_E_IO; }
+    bool ok = true;
+    if (write_text) {                                    // the normalised text, from the host
+        const uint64_t PIECE = (uint64_t)32 << 20;
+        std::vector<uint8_t> buf(PIECE);
+        for (uint64_t o = 0; ok && o < n; o += PIECE) {
+            const uint64_t len = n - o < PIECE ? n - o : PIECE;
+            (void)sufr_hip_normalize(sd->seq + o, buf.data(), len, a->ignore_softmask);
+            ok = pwrite_all(fd, buf.data(), len, L.text_pos + o);
+        }
+    }
+    int failed = 0;
+    if (ok && num_suffixes) {
+        std::vector<Section> secs;
+        secs.push_back({w.d_sa, num_suffixes * (uint64_t)w.width, L.sa_pos + suffix_offset * (uint64_t)w.width});
+        secs.push_back({w.d_lcp, num_suffixes * (uint64_t)w.width, L.lcp_pos + suffix_offset * (uint64_t)w.width});
+        failed = stream_sections(w.device, fd, secs);
+    }
+    if (close(fd) != 0 && !failed) failed = 2;
+    if (!ok) failed = 2;
+    if (failed) {
+        sufr_hip_set_error_(ctx, failed == 2 ? (std::string(outfile) + ": write failed").c_str() : "device-to-host copy of the arrays failed");
+        return failed == 2 ? SUFR_HIP_E_IO : SUFR_HIP_E_HIP;
+    }
+    return 0;
+}
+
 int sufr_hip_shard_build(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const sufr_create_args* a,
                          uint32_t shard_index, uint32_t num_shards, sufr_shard_info* info, sufr_hip_stats* stats)
 {
@@ -732,10 +876,10 @@ int sufr_hip_shard_build(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const 
         sufr_hip_set_error_(ctx, "Cannot use max_query_len and seed_mask together");
         return SUFR_HIP_E_CONFLICT;
     }
-    if (sufr_hip_is_wide_(ctx, sd->seq_len)) {                      // windowed builds are not sharded
-        sufr_hip_set_error_(ctx, "texts of 2^32 - 2^24 bytes and more are built on one GPU (windowed build)");
-        return SUFR_HIP_E_UNSUPPORTED;
-    }
+    if (num_shards == 0 || shard_index >= num_shards) { sufr_hip_set_error_(ctx, "bad shard index"); return SUFR_HIP_E_INVALID; }
+    if (sufr_hip_is_wide_(ctx, sd->seq_len))                       // a shard of the windowed build (ranges of the first 8 bytes)
+        return wide_shard_build(ctx, sd, a, shard_index, num_shards, info, stats);
+    sufr_io_release_ctx_(ctx);
     uint64_t s = 0;
     int rc = sufr_hip_build_resident_(ctx, sd->seq, sd->seq_len, build_flags(a),
                                       a->has_max_query_len ? a->max_query_len : 0, a->seed_mask, shard_index,
@@ -751,6 +895,8 @@ int sufr_hip_shard_write(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, const 
                          int has_prev, uint64_t prev_last_suffix, int write_text)
 {
     if (!ctx || !a || !sd || !outfile) return SUFR_HIP_E_INVALID;
+    if (sufr_hip_is_wide_(ctx, sd->seq_len))
+        return wide_shard_write(ctx, sd, a, outfile, num_suffixes, total_suffixes, suffix_offset, has_prev, prev_last_suffix, write_text);
     int rc;
     if (has_prev && num_suffixes && (rc = sufr_hip_resident_stitch_(ctx, sd->seq_len, prev_last_suffix, nullptr))) return rc;
     int device = 0;

@@ -1491,7 +1491,6 @@ __device__ __forceinline__ uint64_t walk_lcp_packed(const uint8_t* __restrict__ 
     uint64_t lim = n - (a > b ? a : b);
     if (lim > cap) lim = cap;
     const uint32_t K = div_by_bits(64u, bits);                 // whole codes per 64-bit word
-    const int spare = 64 - (int)K * bits;
     uint64_t k = 0;
     ca = cb = 0;
     while (k < lim) {
