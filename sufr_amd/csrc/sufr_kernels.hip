@@ -540,6 +540,26 @@ k_next_tile_blocks(const uint32_t* __restrict__ first_end, uint32_t ntiles, uint
     if (threadIdx.x == 0) block_first[blockIdx.x] = r;
 }
 
+// the three steps in one launch for short texts (<= 16 blocks of 256 tiles = 16 Mb): one workgroup walks the blocks from the
+// end, carrying the nearest run-end tile found so far (two launches fewer on the critical path of a small build)
+__global__ void __launch_bounds__(256)
+k_next_tile_small(const uint32_t* __restrict__ first_end, uint32_t ntiles, uint32_t* __restrict__ next_tile)
+{
+    __shared__ uint32_t s_first[4];
+    const uint32_t nblk = (ntiles + 255u) / 256u;
+    uint32_t carry = RUN_NONE;                             // first tile with a run end in the blocks after b (uniform)
+    for (int b = (int)nblk - 1; b >= 0; b--) {
+        const uint32_t t = (uint32_t)b * 256u + threadIdx.x;
+        const bool has = t < ntiles && first_end[t] != RUN_NONE;
+        uint32_t r = nearest_at_or_after(has, t, s_first);
+        const uint32_t block_first = s_first[0] != RUN_NONE ? s_first[0] : (s_first[1] != RUN_NONE ? s_first[1] : (s_first[2] != RUN_NONE ? s_first[2] : s_first[3]));
+        if (r == RUN_NONE) r = carry;
+        if (t < ntiles) next_tile[t] = r;
+        if (block_first != RUN_NONE) carry = block_first;
+        __syncthreads();                                   // (s_first is rewritten by the next block)
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_next_tile_heads(uint32_t* __restrict__ block_first, uint32_t nblocks)
 {
