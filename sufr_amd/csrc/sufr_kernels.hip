@@ -187,22 +187,34 @@ k_normalize_bytehist(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 // Several buffers cleared by ONE launch (round 5): every hipMemsetAsync is a launch of its own -- ~8 us of the stream with its gap --
 // and a build clears five small ranges before its first kernel and three before every leaf stage: 10 % of a 4.6 Mb build.
 struct ZeroList { unsigned long long p[8]; unsigned long long bytes[8]; uint32_t n; };
+struct ZeroSizes { unsigned long long bytes[8]; };
+// (the pointers are kernel arguments of their own: pointers inside a by-value struct are generic, and a store through one is a
+// flat_store -- tests/test_host_logic.py keeps flat instructions out of the kernels)
+__device__ __forceinline__ void zero_range(uint8_t* __restrict__ p, size_t nb, size_t tid, size_t nth)
+{
+    uint8_t* e = p + nb;
+    uint8_t* a = p + ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u);      // 16-byte body
+    if (a > e) a = e;
+    const size_t head = (size_t)(a - p), nu = (size_t)(e - a) / 16, tail = (size_t)(e - a) - nu * 16;
+    for (size_t i = tid; i < head; i += nth) p[i] = 0;
+    uint4* b = reinterpret_cast<uint4*>(a);
+    for (size_t i = tid; i < nu; i += nth) b[i] = make_uint4(0u, 0u, 0u, 0u);
+    uint8_t* ae = a + nu * 16;
+    for (size_t i = tid; i < tail; i += nth) ae[i] = 0;
+}
 __global__ void __launch_bounds__(256)
-k_zero_ranges(ZeroList z)
+k_zero_ranges(uint8_t* __restrict__ p0, uint8_t* __restrict__ p1, uint8_t* __restrict__ p2, uint8_t* __restrict__ p3,
+              uint8_t* __restrict__ p4, uint8_t* __restrict__ p5, uint8_t* __restrict__ p6, uint8_t* __restrict__ p7, ZeroSizes z)
 {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
-    for (uint32_t r = 0; r < z.n; r++) {
-        uint8_t* p = reinterpret_cast<uint8_t*>(z.p[r]);
-        uint8_t* e = p + z.bytes[r];
-        uint8_t* a = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(p) + 15u) & ~(uintptr_t)15u);     // 16-byte body
-        if (a > e) a = e;
-        uint8_t* ae = a + ((size_t)(e - a) & ~(size_t)15);
-        for (size_t i = tid; i < (size_t)(a - p); i += nth) p[i] = 0;
-        uint4* b = reinterpret_cast<uint4*>(a);
-        const size_t nu = (size_t)(ae - a) / 16;
-        for (size_t i = tid; i < nu; i += nth) b[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (size_t i = tid; i < (size_t)(e - ae); i += nth) ae[i] = 0;
-    }
+    if (z.bytes[0]) zero_range(p0, z.bytes[0], tid, nth);
+    if (z.bytes[1]) zero_range(p1, z.bytes[1], tid, nth);
+    if (z.bytes[2]) zero_range(p2, z.bytes[2], tid, nth);
+    if (z.bytes[3]) zero_range(p3, z.bytes[3], tid, nth);
+    if (z.bytes[4]) zero_range(p4, z.bytes[4], tid, nth);
+    if (z.bytes[5]) zero_range(p5, z.bytes[5], tid, nth);
+    if (z.bytes[6]) zero_range(p6, z.bytes[6], tid, nth);
+    if (z.bytes[7]) zero_range(p7, z.bytes[7], tid, nth);
 }
 
 // ---------------------------------------------------------------------------------------------
