@@ -2309,7 +2309,8 @@ k_scan_reduce(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restr
 }
 
 __global__ void __launch_bounds__(256)
-k_scan_partials(uint32_t* __restrict__ partial, uint32_t nblocks, unsigned long long* __restrict__ total)
+k_scan_partials(uint32_t* __restrict__ partial, uint32_t nblocks, unsigned long long* __restrict__ total,
+                unsigned long long* __restrict__ total2 = nullptr /* a second place for the total (round 5: instead of a device-to-device copy, a launch of its own) */)
 {
     // single workgroup, sequential chunks of 256
     __shared__ uint32_t s_w[4];
@@ -2336,6 +2337,7 @@ k_scan_partials(uint32_t* __restrict__ partial, uint32_t nblocks, unsigned long 
         __syncthreads();
     }
     if (threadIdx.x == 0 && total) *total = (unsigned long long)s_carry;
+    if (threadIdx.x == 0 && total2) *total2 = (unsigned long long)s_carry;
 }
 
 __global__ void __launch_bounds__(256)
@@ -2377,7 +2379,7 @@ static constexpr uint32_t SCAN1_MAX = 1024u * SCAN1_PER;
 
 __global__ void __launch_bounds__(1024)
 k_scan_small(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restrict__ out,
-             unsigned long long* __restrict__ total)
+             unsigned long long* __restrict__ total, unsigned long long* __restrict__ total2 = nullptr)
 {
     __shared__ uint32_t s_w[16];
     const uint32_t b0 = threadIdx.x * SCAN1_PER;
@@ -2398,6 +2400,7 @@ k_scan_small(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restri
 #pragma unroll
     for (int k = 0; k < SCAN1_PER; k++) { if (b0 + k < count) out[b0 + k] = run; run += v[k]; }
     if (threadIdx.x == 1023 && total) *total = (unsigned long long)run;
+    if (threadIdx.x == 1023 && total2) *total2 = (unsigned long long)run;
 }
 
 // ... and for arrays of up to SCANM_MAX values (per-cell tables of a level of a small genome, window flags): the same workgroup
@@ -2407,7 +2410,7 @@ static constexpr uint32_t SCANM_MAX = 16u * SCAN1_MAX;
 
 __global__ void __launch_bounds__(1024)
 k_scan_medium(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restrict__ out,
-              unsigned long long* __restrict__ total)
+              unsigned long long* __restrict__ total, unsigned long long* __restrict__ total2 = nullptr)
 {
     __shared__ uint32_t s_w[2][16];
     uint32_t carry = 0;
@@ -2453,6 +2456,7 @@ k_scan_medium(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restr
         }
     }
     if (threadIdx.x == 0 && total) *total = (unsigned long long)carry;
+    if (threadIdx.x == 0 && total2) *total2 = (unsigned long long)carry;
 }
 
 // ---------------------------------------------------------------------------------------------
