@@ -252,3 +252,20 @@ def test_no_flat_instructions_in_the_kernels():
     assert not bad, bad[:5]
     # and no kernel spills to scratch
     assert all(int(v) == 0 for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", asm))
+
+
+def test_integration_md_names_every_export():
+    """INTEGRATION.md is the binding a libsufr maintainer would write from: every function include/*.h declares is named there
+    (the block of section 2, or the list of the exports it leaves out)"""
+    from pathlib import Path
+    ROOT = Path(__file__).resolve().parent.parent
+    text = (ROOT / "INTEGRATION.md").read_text()
+    missing = []
+    for h in ("sufr_hip.h", "sufr_query.h"):
+        src = (ROOT / "include" / h).read_text()
+        for name in sorted(set(re.findall(r"\b(sufr_[a-z0-9_]+)\s*\(", src))):
+            if f"}} {name};" in src or f"struct {name}" in src:       # (a type that a comment happens to follow with a bracket)
+                continue
+            if name not in text:
+                missing.append(name)
+    assert not missing, missing
