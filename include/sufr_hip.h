@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SUFR_HIP_ABI_VERSION 2
+#define SUFR_HIP_ABI_VERSION 3
 
 /* .sufr serialisation version, libsufr/src/types.rs:16 */
 #define SUFR_OUTFILE_VERSION 6
@@ -85,6 +85,11 @@ typedef struct sufr_hip_stats {
     float host_read_s;          /* sequence file -> text */
     float host_build_s;         /* H2D + device build (+ first-use allocations) */
     float host_write_s;         /* D2H + .sufr written */
+    /* ABI 3 (round 6): DNA texts with a few bytes outside {$ % A C G N T} -- IUPAC codes, another delimiter -- keep the fixed 3-bit
+     * code table: the build runs on 'N' in their place and the suffixes whose comparisons reached one are re-placed afterwards */
+    uint32_t num_exceptions;    /* such bytes in the text (0: none, or the build took the general code table) */
+    float ms_exceptions;        /* marking + re-placing (part of ms_deep and ms_total) */
+    uint64_t num_reinserted;    /* suffixes re-placed by whole-text comparison */
 } sufr_hip_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -1,6 +1,8 @@
 """Device time of one build for the input classes of DESIGN.md section 4 ("other input classes"), second build on a
 warm context:   python profiles/input_classes.py [class ...]
-Classes: human, human_dna (soft-masked repeats indexed), human_amb, human_amb_soft, protein, all_a, dup100k, copies300."""
+Classes: human, human_dna (soft-masked repeats indexed), human_amb, human_amb_soft, protein, all_a, dup100k, copies300,
+human_iupac (the headline text with 50 IUPAC ambiguity codes planted, as an NCBI GRCh38 carries them), human_hash (the headline
+text with '#' between the sequences: any byte outside {$ % A C G N T} takes a DNA build off the fixed 3-bit code table)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +22,13 @@ def make(name):
     if name.startswith("human"):
         x, _ = synth.syn_human(3_100_000_000, seed=4, device=dev)
         flags = {"human": dict(ignore_softmask=True), "human_dna": {}, "human_amb": dict(allow_ambiguity=True),
-                 "human_amb_soft": dict(allow_ambiguity=True, ignore_softmask=True)}[name]
+                 "human_amb_soft": dict(allow_ambiguity=True, ignore_softmask=True),
+                 "human_iupac": dict(ignore_softmask=True), "human_hash": dict(ignore_softmask=True)}[name]
+        if name == "human_iupac":
+            at = torch.randint(1000, x.numel() - 1000, (50,), generator=g, device=dev)
+            x[at] = torch.tensor(list(b"RYKMSWBDHV" * 5), dtype=torch.uint8, device=dev)
+        if name == "human_hash":
+            x[x == ord("%")] = ord("#")
         return x, dict(is_dna=True, **flags)
     if name == "protein":
         aa = torch.tensor(list(b"ACDEFGHIKLMNPQRSTVWY"), dtype=torch.uint8, device=dev)

@@ -11,6 +11,7 @@ from sufr_amd import synth
 CASES = [
     ("human -s 111010010100110111", synth.syn_human, 3_100_000_000, 4, dict(is_dna=True, seed_mask="111010010100110111", num_partitions=800)),
     ("human --dna -n 800 (Makefile:79)", synth.syn_human, 3_100_000_000, 4, dict(is_dna=True, num_partitions=800)),
+    ("human --dna -m 16", synth.syn_human, 3_100_000_000, 4, dict(is_dna=True, max_query_len=16, num_partitions=800)),
     ("elegans -m 12", synth.syn_elegans, 100_286_401, 2, dict(is_dna=True, max_query_len=12, num_partitions=64)),
     ("elegans --dna", synth.syn_elegans, 100_286_401, 2, dict(is_dna=True, num_partitions=64)),
     ("ecoli -m 16", synth.syn_ecoli, 4_641_652, 1, dict(is_dna=True, max_query_len=16)),

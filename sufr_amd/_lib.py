@@ -49,6 +49,7 @@ class Stats(C.Structure):
         ("ms_partition", C.c_float), ("ms_passes", C.c_float), ("ms_finish", C.c_float),
         ("ms_deep", C.c_float), ("host_read_s", C.c_float), ("host_build_s", C.c_float),
         ("host_write_s", C.c_float),
+        ("num_exceptions", C.c_uint32), ("ms_exceptions", C.c_float), ("num_reinserted", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -274,7 +274,7 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
                 uint32_t* __restrict__ first_end, uint64_t* __restrict__ run_ends,
                 uint64_t* __restrict__ tile_any, uint8_t* __restrict__ packed, uint32_t elig_codes,
                 uint64_t chunk, uint32_t ngroups, uint32_t* __restrict__ rawtab, uint32_t* __restrict__ presbits,
-                uint64_t* __restrict__ startbits)
+                uint64_t* __restrict__ startbits, uint32_t* __restrict__ exc_pos, uint8_t* __restrict__ exc_byte, uint32_t exc_cap)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem);                                   // TP_RAW_BINS
@@ -350,6 +350,27 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
                 y[k][q] = yy;
             }
             if (p + 16 <= n) {
+                if (((na | nb) & 0xfu) != 0u) {
+                    // a byte outside the table among these 16 (an IUPAC code, another delimiter: a few dozen positions of a real
+                    // assembly): the text of THIS build carries 'N' there (code 6, same eligibility) and the position joins the
+                    // exception list -- the suffixes whose comparisons reached it are re-placed by exc_reinsert after the build
+                    // (everything of these 16 bytes is computed again, so that nothing of the first attempt stays live beside it: the
+                    // kernel sits at 127 of its 128 registers, and the forms that patch the first attempt spill)
+                    vh = 0; vl = 0; na = 0; nb = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        uint32_t t = s_tab[(ws[e >> 2] >> (8 * (e & 3))) & 0xffu];
+                        if ((t & 0xffu) == 0u) {
+                            const unsigned long long at = atomicAdd(&counts[9], 1ull);
+                            if (at < (unsigned long long)exc_cap) { exc_pos[at] = (uint32_t)(p + e); exc_byte[at] = (uint8_t)(t >> 8); }
+                            t = (0x4eu << 8) | 6u;
+                        }
+                        const uint32_t c = t & 0xffu;
+                        if ((e & 3) == 0) y[k][e >> 2] = 0;
+                        y[k][e >> 2] |= (t >> 8) << (8 * (e & 3));
+                        if (e < 8) { vh = (vh << 3) | c; na += 1u << (4 * c); } else { vl = (vl << 3) | c; nb += 1u << (4 * c); }
+                    }
+                }
                 *reinterpret_cast<uint4*>(out + p) = make_uint4(y[k][0], y[k][1], y[k][2], y[k][3]);
             } else {
                 // the text ends inside these 16 bytes (or before them): nothing past the end is a character
@@ -359,7 +380,12 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
                 for (int e = 0; e < 16; e++) {
                     uint32_t c = 0;
                     if (p + e < n) {
-                        const uint32_t t = s_tab[(ws[e >> 2] >> (8 * (e & 3))) & 0xffu];
+                        uint32_t t = s_tab[(ws[e >> 2] >> (8 * (e & 3))) & 0xffu];
+                        if ((t & 0xffu) == 0u) {                                   // (see above)
+                            const unsigned long long at = atomicAdd(&counts[9], 1ull);
+                            if (at < (unsigned long long)exc_cap) { exc_pos[at] = (uint32_t)(p + e); exc_byte[at] = (uint8_t)(t >> 8); }
+                            t = (0x4eu << 8) | 6u;
+                        }
                         c = t & 0xffu;
                         m[e >> 2] |= (t >> 8) << (8 * (e & 3));
                         out[p + e] = (uint8_t)(t >> 8);
@@ -393,7 +419,7 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 uint32_t t = 0;
-                if (p + e < n) t = s_tab[in[p + e]];
+                if (p + e < n) { t = s_tab[in[p + e]]; if ((t & 0xffu) == 0u) t = (0x4eu << 8) | 6u; }     // (listed by the tile's owner)
                 c4 = (c4 << 3) | (t & 0xffu);
                 if (e == 0) b0 = t >> 8;
             }
@@ -511,6 +537,14 @@ k_text_pass_dna(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint6
         const uint32_t b = s_pres[threadIdx.x];
         if (b) atomicOr(&presbits[threadIdx.x], b);
     }
+}
+
+// the listed bytes (k_text_pass_dna: bytes outside the fixed table, built as 'N') back into the normalised text (sufr_exc.inc)
+__global__ void __launch_bounds__(256)
+k_exc_restore(uint8_t* __restrict__ text, const uint32_t* __restrict__ pos, const uint8_t* __restrict__ byte, uint32_t E)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < E) text[pos[i]] = byte[i];
 }
 
 // rawtot[v] = suffix starts whose first digit is v (all groups); bit v of occurs[] set iff the 5-mer v occurs anywhere
@@ -2496,6 +2530,33 @@ k_mql_flags(uint32_t* __restrict__ lcp, uint32_t s, uint32_t L, uint32_t* __rest
     member[r] = (tie || nxt) ? 1u : 0u;
 }
 
+// The capped build proper (round 6; sufr_launch.inc "mql_fast": L fits the key).  Records are keyed by their first L characters
+// and, below them, the top bits of the complement of their position (k_msd_part_text<.., POS>): the MSD levels and the leaf sort
+// order equal L-prefixes by descending position as far as those bits tell.  What still ties is keyed by the whole complement
+// (k_pos_keys: one level, no text read), and every LCP the key comparisons computed beyond L characters is cut back to L.
+__global__ void __launch_bounds__(256)
+k_pos_keys(const uint32_t* __restrict__ idx, uint32_t m, uint64_t* __restrict__ keys)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < m) keys[t] = (uint64_t)(~idx[t]) << 32;
+}
+__global__ void __launch_bounds__(256)
+k_mql_cap(uint32_t* __restrict__ lcp, uint32_t s, uint32_t L)
+{
+    // 16 bytes per lane; the stores are skipped where nothing changes (most ranks of a long cap)
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = q * 4u;
+    if (r + 4u <= s) {
+        uint4 v = reinterpret_cast<const uint4*>(lcp)[q];
+        if (v.x > L || v.y > L || v.z > L || v.w > L) {
+            v.x = v.x > L ? L : v.x; v.y = v.y > L ? L : v.y; v.z = v.z > L ? L : v.z; v.w = v.w > L ? L : v.w;
+            reinterpret_cast<uint4*>(lcp)[q] = v;
+        }
+    } else {
+        for (uint32_t i = r; i < s; i++) if (lcp[i] > L) lcp[i] = L;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_mql_compact(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ lcp,
               const uint32_t* __restrict__ member, const uint32_t* __restrict__ off, uint32_t s, uint32_t L,
@@ -2907,6 +2968,7 @@ k_widen(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t co
 #include "sufr_runs.inc"
 #include "sufr_launch.inc"
 #include "sufr_wide.inc"
+#include "sufr_exc.inc"
 #include "sufr_capi.inc"
 #include "../../include/sufr_query.h"
 #include "sufr_search.inc"

@@ -1,0 +1,194 @@
+"""DNA texts with bytes outside {$ % A C G N T} (IUPAC ambiguity codes, another delimiter) keep the fixed 3-bit code table
+(sufr_amd/csrc/sufr_exc.inc): the build runs on 'N' in their place and the suffixes whose comparisons reached such a byte are
+re-placed by whole-text comparison.  Every case: whole SA and LCP equal the CPU oracle's (which compares raw bytes,
+sufr_builder.rs:346-394), the normalised text handed back carries the original bytes, and the stats say the path was taken."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sufr_amd
+from sufr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+IUPAC = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)
+
+
+def _acgt(rng, n):
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+
+
+def _check(oracle, raw, *, expect_exceptions=True, shards=1, **kw):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    db = sufr_amd.DeviceBuilder(0)
+    x = torch.from_numpy(raw).cuda()
+    sa, lcp = db.sort(x, raw_text=True, **kw)
+    st = db.stats
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    norm = oracle.normalize(raw, kw.get("ignore_softmask", False))
+    okw = {k: v for k, v in kw.items() if k in ("is_dna", "allow_ambiguity")}
+    osa, olcp, _ = oracle.build(norm, threads=min(16, os.cpu_count() or 1), **okw)
+    assert gsa.size == osa.size
+    bad = np.nonzero(gsa != osa)[0]
+    assert bad.size == 0, f"SA differs at rank {bad[0]} of {osa.size}: got {gsa[bad[0]]} want {osa[bad[0]]} ({bad.size} ranks differ)"
+    bad = np.nonzero(glcp != olcp)[0]
+    assert bad.size == 0, f"LCP differs at rank {bad[0]} of {osa.size}: got {glcp[bad[0]]} want {olcp[bad[0]]} ({bad.size} ranks differ)"
+    if expect_exceptions:
+        assert st.num_exceptions > 0 and st.bits_per_char == 3, (st.num_exceptions, st.bits_per_char)
+    info = (st.num_exceptions, st.num_reinserted)
+    db.close()
+    return info
+
+
+@pytest.mark.parametrize("n", [40, 1000, 70_000, 3_000_000])
+@pytest.mark.parametrize("amb", [False, True])
+def test_scattered_iupac_codes_equal_oracle(oracle, n, amb):
+    rng = np.random.default_rng(n + amb)
+    raw = _acgt(rng, n)
+    k = max(1, min(60, n // 20))
+    raw[rng.integers(0, n - 1, k)] = IUPAC[rng.integers(0, 10, k)]
+    raw[-1] = ord("$")
+    small = 64 * k > n                           # (more than one such byte in 64: the general table)
+    exc, re = _check(oracle, raw, is_dna=True, allow_ambiguity=amb, expect_exceptions=not small)
+    if not small:
+        assert 0 < exc <= k and re >= (exc if amb else 1)
+
+
+@pytest.mark.parametrize("soft", [False, True])
+def test_softmasked_text_with_iupac_n_runs_and_delimiters(oracle, soft):
+    """the shape of a real assembly: lowercase repeats (also lowercase IUPAC letters: upper-cased, or 'N' under
+    --ignore-softmask), N runs, '%' between sequences, IUPAC codes next to all of them"""
+    x, _ = synth.syn_human(2_000_000, seed=11)
+    raw = x.numpy().copy()
+    rng = np.random.default_rng(5)
+    # (N runs stay below 1000: with two runs of >= 1000 'N' the reference's own --allow-ambiguity order is approximate,
+    # sufr_builder.rs:302-307, and so is the oracle's -- DESIGN.md section 2)
+    isn = np.nonzero((raw == ord("N")) | (raw >= 97))[0]      # (lowercase becomes 'N' under --ignore-softmask)
+    raw[isn[::700]] = ord("A")
+    at = rng.integers(100, raw.size - 100, 40)
+    raw[at] = IUPAC[rng.integers(0, 10, 40)]
+    raw[at[:10] + 1] = IUPAC[rng.integers(0, 10, 10)] | 0x20          # lowercase ones
+    n_at = np.nonzero(raw == ord("N"))[0]
+    raw[n_at[rng.integers(0, n_at.size, 5)]] = ord("R")               # inside N runs
+    pc = np.nonzero(raw == ord("%"))[0]
+    raw[pc[0] + 1] = ord("Y"); raw[pc[1] - 1] = ord("K")
+    raw[0] = ord("M"); raw[-2] = ord("S")
+    _check(oracle, raw, is_dna=True, ignore_softmask=soft)
+    _check(oracle, raw, is_dna=True, ignore_softmask=soft, allow_ambiguity=True)
+
+
+def test_other_delimiter_is_an_exception_byte(oracle):
+    """`-D '#'`: every delimiter is a byte outside the table; also bytes below '$' and above 'T'"""
+    rng = np.random.default_rng(8)
+    raw = _acgt(rng, 500_000)
+    raw[np.arange(5_000, raw.size - 1, 5_000)] = ord("#")
+    raw[[17, 4_000, 250_000]] = [ord("!"), ord("Z"), ord("*")]
+    raw[-1] = ord("$")
+    exc, _ = _check(oracle, raw, is_dna=True)
+    assert exc == 99 + 2                     # (250 000 is one of the delimiters)
+    _check(oracle, raw, is_dna=True, allow_ambiguity=True)
+
+
+def test_iupac_codes_inside_repeats_reach_far(oracle):
+    """copies of a long segment that differ ONLY in an IUPAC letter (R in one, N in another, T in a third, the letter missing
+    in the rest): the comparisons of thousands of suffixes before the letter reach it, and the order of the copies is decided
+    by the raw byte ('N' < 'R' < 'T') -- the re-placed suffixes are most of the family"""
+    rng = np.random.default_rng(21)
+    raw = _acgt(rng, 1_500_000)
+    seg = _acgt(rng, 6_000)
+    for i, c in enumerate(b"RNTRYAGK"):
+        s = seg.copy()
+        s[4_000] = c
+        raw[100_000 + i * 150_000:100_000 + i * 150_000 + 6_000] = s
+    raw[-1] = ord("$")
+    exc, re = _check(oracle, raw, is_dna=True)
+    assert exc == 4 and re > 3 * 3_000
+    _check(oracle, raw, is_dna=True, allow_ambiguity=True)
+
+
+def test_runs_and_clusters_of_exception_bytes(oracle):
+    """runs of one IUPAC letter (under -a every position of the run is a suffix; in the build they are a run of 'N': the
+    closed-form run buckets), alternating letters, a run that ends the text"""
+    rng = np.random.default_rng(33)
+    raw = _acgt(rng, 800_000)
+    raw[10_000:10_700] = ord("R")
+    raw[300_000:300_050] = np.resize(np.frombuffer(b"RY", dtype=np.uint8), 50)
+    raw[500_000:500_400] = ord("N"); raw[500_200] = ord("R")          # an N run broken by one letter
+    raw[-40:-1] = ord("W")
+    raw[-1] = ord("$")
+    _check(oracle, raw, is_dna=True)
+    exc, re = _check(oracle, raw, is_dna=True, allow_ambiguity=True)
+    assert exc == 700 + 50 + 1 + 39 and re >= exc
+
+
+def test_many_exception_bytes_fall_back_to_the_general_table(oracle):
+    """more than one byte in 64 outside the table: not a DNA text with a few ambiguity codes -- the general code table as
+    before (and the text handed back is still the caller's)"""
+    rng = np.random.default_rng(2)
+    raw = np.frombuffer(b"ACGTRYKM", dtype=np.uint8)[rng.integers(0, 8, 200_000)].copy()
+    raw[-1] = ord("$")
+    exc, _ = _check(oracle, raw, expect_exceptions=False, is_dna=True)
+    assert exc == 0
+
+
+def test_sharded_builds_with_exception_bytes_concatenate(oracle):
+    """a sharded build takes the general table (the first digit of a re-placed suffix decides its shard): the shards still
+    concatenate to the oracle's arrays"""
+    rng = np.random.default_rng(4)
+    raw = _acgt(rng, 400_000)
+    raw[rng.integers(0, raw.size - 1, 30)] = IUPAC[rng.integers(0, 10, 30)]
+    raw[-1] = ord("$")
+    x = torch.from_numpy(raw).cuda()
+    db = sufr_amd.DeviceBuilder(0)
+    parts_sa, parts_lcp = [], []
+    for k in range(3):
+        sa, lcp = db.sort(x, raw_text=True, is_dna=True, shard_index=k, num_shards=3)
+        parts_sa.append(sa.cpu().numpy().view(np.uint32).copy()); parts_lcp.append(lcp.cpu().numpy().view(np.uint32).copy())
+    db.close()
+    osa, olcp, _ = oracle.build(raw, is_dna=True, threads=8)
+    gsa = np.concatenate(parts_sa); glcp = np.concatenate(parts_lcp)
+    assert np.array_equal(gsa, osa)
+    starts = np.cumsum([0] + [p.size for p in parts_sa[:-1]])
+    keep = np.ones(osa.size, dtype=bool); keep[starts[1:]] = False      # (a shard's first LCP is the stitch's)
+    assert np.array_equal(glcp[keep], olcp[keep])
+
+
+def test_host_buffer_abi_returns_the_original_bytes(oracle):
+    """sufr_hip_build_u32 (what the Rust shim binds): norm_text_out carries the IUPAC letters, not the 'N' of the build"""
+    rng = np.random.default_rng(9)
+    raw = _acgt(rng, 100_000)
+    raw[[5, 50_000, 99_990]] = [ord("R"), ord("y"), ord("K")]
+    raw[-1] = ord("$")
+    ctx = sufr_amd.Context(0)
+    args = sufr_amd.SufrBuilderArgs(text=raw, is_dna=True)
+    b = sufr_amd.SufrBuilder(args, index_width=4, ctx=ctx, write=False)
+    norm = oracle.normalize(raw, False)
+    assert np.array_equal(b.text, norm) and norm[50_000] == ord("Y")
+    osa, olcp, _ = oracle.build(norm, is_dna=True, threads=8)
+    assert np.array_equal(b.suffix_array, osa) and np.array_equal(b.lcp, olcp)
+    ctx.close()
+
+
+def test_max_query_len_and_windows_with_exception_bytes(oracle):
+    """-m L on top of the re-placed arrays (same canonical form as without exception bytes), and the windowed build"""
+    rng = np.random.default_rng(12)
+    raw = _acgt(rng, 300_000)
+    raw[50_000:50_300] = raw[150_000:150_300]
+    raw[rng.integers(0, raw.size - 1, 25)] = IUPAC[rng.integers(0, 10, 25)]
+    raw[-1] = ord("$")
+    x = torch.from_numpy(raw).cuda()
+    osa, olcp, _ = oracle.build(raw, is_dna=True, threads=8)
+    db = sufr_amd.DeviceBuilder(0)
+    sa, lcp = db.sort(x, raw_text=True, is_dna=True, max_query_len=11)
+    gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
+    assert np.array_equal(glcp, np.minimum(olcp, 11))
+    assert np.array_equal(np.sort(gsa), np.sort(osa))
+    pre = lambda p: bytes(raw[p:p + 11])
+    assert [pre(p) for p in gsa[:20_000]] == [pre(p) for p in osa[:20_000]]
+    db.ctx.set_window(70_000, 5_000)
+    wsa, wlcp = db.sort(x, raw_text=True, is_dna=True, index_width=8)
+    assert np.array_equal(wsa.cpu().numpy().astype(np.uint32), osa) and np.array_equal(wlcp.cpu().numpy().astype(np.uint32), olcp)
+    db.ctx.set_window(0, 0)
+    db.close()

@@ -24,7 +24,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     L = sufr_amd.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sufr_hip_abi_version() == 2
+    assert L.sufr_hip_abi_version() == 3
     # the shared object itself (not just the ctypes table) exports them
     nm = subprocess.run(["nm", "-D", "--defined-only", str(sufr_amd.LIB_PATH)], capture_output=True, text=True).stdout
     for name in declared:
