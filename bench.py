@@ -198,6 +198,60 @@ def e2e_create(text_cpu: np.ndarray, starts, flags: dict, partitions: int, s_tot
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def host_abi(text_cpu: np.ndarray, flags: dict, partitions: int, reps: int = 3):
+    """The host-buffer ABI (sufr_hip_build_u32: the call INTEGRATION.md section 3 puts inside SufrBuilder::new) on the same text:
+    pageable host text in, normalised text + SA + LCP out into freshly allocated pageable arrays (their first-touch faults are
+    part of the call).  PCIe-inclusive: reported next to `value`, never as `value`."""
+    import ctypes as C
+    from sufr_amd import _lib
+    try:
+        n = text_cpu.size
+        ctx = sufr_amd.Context(0)
+        L = _lib.lib()
+        fl = _lib.FLAG_RAW_TEXT | (_lib.FLAG_DNA if flags.get("is_dna") else 0) | \
+            (_lib.FLAG_IGNORE_SOFTMASK if flags.get("ignore_softmask") else 0) | (_lib.FLAG_ALLOW_AMBIGUITY if flags.get("allow_ambiguity") else 0)
+        calls = []
+        for _ in range(reps):
+            norm = np.empty(n, dtype=np.uint8); sa = np.empty(n, dtype=np.uint32); lcp = np.empty(n, dtype=np.uint32)
+            ns = C.c_uint64(0); st = _lib.Stats()
+            t0 = time.perf_counter()
+            rc = L.sufr_hip_build_u32(ctx.handle, text_cpu.ctypes.data, n, fl, 0, None, partitions, 42, norm.ctypes.data,
+                                      sa.ctypes.data, lcp.ctypes.data, n, C.byref(ns), C.byref(st))
+            dt = time.perf_counter() - t0
+            ctx.check(rc)
+            calls.append({"seconds": round(dt, 4), "h2d_s": round(st.host_read_s, 4), "build_s": round(st.host_build_s, 4),
+                          "d2h_s": round(st.host_write_s, 4)})
+            s = ns.value
+            del norm, sa, lcp
+        ctx.close()
+        best = min(calls, key=lambda c: c["seconds"])
+        gb = (2 * n + 8 * s) / 1e9
+        return {"entry_point": "sufr_hip_build_u32", "seconds": best["seconds"], "suffixes_per_s": s / best["seconds"],
+                "pcie_gb": round(gb, 2), "gb_per_s": round(gb / best["seconds"], 1), "calls": calls,
+                "what": "pageable host buffers both ways: H2D of the text, device build, D2H of the normalised text + SA + LCP "
+                        "(first call: pinned staging buffers and the workspace are allocated)"}
+    except Exception as e:      # the headline number must not depend on host memory
+        return {"error": repr(e)[:200]}
+
+
+def store_floor(s_total: int, text_len: int, bins: int):
+    """What the memory side takes of the partition kernel's STORE PATTERN alone (profiles/micro/scatter_write.hip --floor): the same
+    number of 12-byte records in runs of (records per 65 536-position tile / first digits) over the same number of first digits,
+    cursors claimed with returning atomics, from a resident grid of one workgroup per CU -- no text, no ranking.  The kernel cannot
+    be faster than this with this record format and tile size; measured live, outside the timed region."""
+    import subprocess
+    exe = Path(__file__).resolve().parent / "profiles" / "micro" / "scatter_write"
+    if not exe.exists() or bins <= 0:
+        return None
+    run = max(1, round(s_total / max(1, text_len) * 65536 / bins))
+    try:
+        r = subprocess.run([str(exe), "--floor", str(s_total), str(bins), str(run)], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if r.returncode == 0 and lines else None
+    except Exception:
+        return None
+
+
 def write_fasta(fa: Path, text_cpu: np.ndarray, starts):
     body = text_cpu[:-1]
     cuts = list(starts) + [body.size + 1]
@@ -314,6 +368,12 @@ def launch_ranks(args) -> int:
     <same arguments>` as a child process and return its exit code.  Called before any HIP / torch.cuda call (counting
     devices does not initialise the GPU on this image); the child's ranks do the GPU work."""
     import subprocess
+    if args.share_device and args.backend != "gloo":
+        # N RCCL ranks on one device die with a duplicate-GPU error: say so here instead (advisor r5)
+        print("bench.py: --share-device puts every rank on cuda:0 and needs the host-side exchange: add  --backend gloo", file=sys.stderr)
+        return 2
+    # (torch.cuda.device_count() reads the device list without initialising the GPU on this image -- unlike
+    # torch.cuda.is_available() or any HIP call --, and it honours the visibility masks a KFD topology walk would not)
     have = torch.cuda.device_count()
     if not args.share_device and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but this box shows {have} GPU(s).  One rank per GPU over RCCL needs {args.gpus}; to "
@@ -340,6 +400,9 @@ def file_sha256(path) -> str:
 
 
 def main():
+    if os.environ.get("SUFR_BENCH_STACKS_AFTER"):       # debugging aid: every rank dumps its Python stacks after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SUFR_BENCH_STACKS_AFTER"]), repeat=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -408,11 +471,27 @@ def main():
         label = f"{os.path.basename(fasta)} ({len(starts)} sequences) with the flags of: {label}"
         data = "real"
         bases = text.numel() - 1
+    elif args.share_device and world > 1:
+        # N generators time-slicing ONE device crawl (eight of them at 3.1 Gb were still in their first kernel launches after
+        # 70 s; one alone takes ~5 s): the ranks generate one after the other
+        text = starts = None
+        for r in range(world):
+            if r == rank:
+                text, starts = gen(bases, device=dev)
+                torch.cuda.synchronize()
+            dist.barrier()
     else:
         text, starts = gen(bases, device=dev)   # identical on every rank (same seed, same device type)
     torch.cuda.synchronize()
     n = text.numel()
+    t_prog = time.perf_counter()
 
+    def progress(what: str):
+        """one line per phase and rank on stderr when several ranks run (a rank that dies or starves is then visible in the log)"""
+        if world > 1:
+            print(f"[bench rank {rank}/{world}] {what} at {time.perf_counter() - t_prog:.1f} s", file=sys.stderr, flush=True)
+
+    progress(f"text ready (n = {n})")
     builder = sufr_amd.DeviceBuilder(local_rank)
     placement_ms = []
     out_sa = [None] * vshards
@@ -458,8 +537,24 @@ def main():
             totals["outs"] = outs
         return sa, lcp
 
-    # size the output arrays once (first call allocates n entries; later calls reuse them)
-    sa, lcp = step()
+    # size the output arrays once.  One shard: the first call allocates n entries.  Shards: eight ranks that each take 8 n bytes
+    # for the sizing call (24.8 GB at 3.1 Gb, beside text, generator scratch and workspace) do not fit ONE 288 GB device -- the
+    # --share-device rehearsal of round 6 sat in the allocator for 50 minutes --: a shard's arrays are tried at 1.4 x its even
+    # share first and at n only if the build reports that it needs more (SUFR_HIP_E_CAPACITY).
+    if num_shards > 1:
+        guess = int(n / num_shards * 1.4) + (1 << 20)
+        if guess < n:
+            out_sa = [torch.empty(guess, dtype=torch.int32, device=dev) for _ in range(vshards)]
+            out_lcp = [torch.empty(guess, dtype=torch.int32, device=dev) for _ in range(vshards)]
+    try:
+        sa, lcp = step()
+    except Exception as e:          # noqa: BLE001 -- a shard above the guess: the full-size arrays after all
+        if num_shards == 1 or "capacity" not in str(e).lower():
+            raise
+        out_sa = [None] * vshards; out_lcp = [None] * vshards
+        torch.cuda.empty_cache()
+        sa, lcp = step()
+    progress("first build done")
     if vshards == 1:
         cap = int(builder.num_suffixes * 1.02) + 1024
         out_sa = [torch.empty(cap, dtype=torch.int32, device=dev)]
@@ -476,6 +571,8 @@ def main():
     # (profiles/README.md: a plain 12 GB copy runs at 4.4-5.2 TB/s depending on the allocation).  The bench
     # creates a few contexts, builds on each (placement_ms) and times the one with the MEDIAN build time: `value`
     # is what a user's single context typically gets; value_best is the same count over the fastest placement.
+    if args.share_device and world > 1:
+        args.placement_trials = 1       # (N ranks on ONE device: three contexts per rank are 24 workspaces of ~10 GB at N = 8)
     if args.placement_trials > 1:
         cands = [builder]
         for _ in range(args.placement_trials - 1):
@@ -494,6 +591,7 @@ def main():
         torch.cuda.empty_cache()
     for _ in range(max(0, args.warmup)):
         step()
+    progress("warm-up done")
 
     def barrier():
         torch.cuda.synchronize()
@@ -633,7 +731,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(text[:sample_bases].cpu().numpy(), flags, partitions, full_text=full)
         if world == 1 and not args.no_e2e:
             builder.close()          # the CLI is its own process with its own context: free this one's HBM first
-            out["e2e_create"] = e2e_create(text.cpu().numpy(), starts, flags, partitions, s_total, want_hash=args.e2e_hash)
+            text_cpu = text.cpu().numpy()
+            if st.get("partition_variant"):
+                del text
+                torch.cuda.empty_cache()
+                fl = store_floor(s_total, n, int(st.get("top_hi", 0)) - int(st.get("top_lo", 0)))
+                if fl:
+                    out["roofline"]["store_floor_ms"] = fl["store_floor_ms"]
+                    out["roofline"]["store_floor"] = {k: fl[k] for k in ("records", "bins", "run", "grid", "bytes")}
+                    out["roofline"]["store_floor"]["what"] = ("the kernel's store pattern alone (12-byte records, runs of `run` records over "
+                                                              "`bins` first digits, resident grid): profiles/micro/scatter_write.hip --floor")
+            if host_memory_gb() >= 10 * n / 2**30 + 8:
+                out["host_abi"] = host_abi(text_cpu, flags, partitions)
+            out["e2e_create"] = e2e_create(text_cpu, starts, flags, partitions, s_total, want_hash=args.e2e_hash)
         if e2e_multi is not None:
             out["e2e_create"] = e2e_multi
         print(json.dumps(out), flush=True)

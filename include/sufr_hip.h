@@ -81,7 +81,9 @@ typedef struct sufr_hip_stats {
                                    (k_gather_keys, k_group_sort_*, k_plan_windows, k_finish, prefix doubling) and the buckets of one
                                    repeated symbol placed by counting (sufr_runs.inc); their records are in deep_records only as far as
                                    they went through the levels */
-    /* host phases of sufr_hip_create_file (seconds; 0 from the other entry points) */
+    /* host phases (seconds).  sufr_hip_create_file: as named.  sufr_hip_build_u32 / _u64 (host buffers; round 6): host_read_s =
+     * the caller's text to the device, host_build_s = device build (+ first-use allocations), host_write_s = text + SA + LCP
+     * into the caller's buffers.  0 from the device-resident entry points. */
     float host_read_s;          /* sequence file -> text */
     float host_build_s;         /* H2D + device build (+ first-use allocations) */
     float host_write_s;         /* D2H + .sufr written */

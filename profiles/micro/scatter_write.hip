@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -157,8 +158,45 @@ k_stream(Rec* __restrict__ out, uint64_t records)
         out[j] = Rec{(uint32_t)j, 1u, 2u};
 }
 
+// ./scatter_write --floor <records> <bins> <run>: ONE number for bench.py's roofline record -- the store pattern of the partition
+// kernel alone (r-record runs of 12-byte records over `bins` first digits, per-(group, bin) cursors claimed with returning atomics)
+// from a resident grid of one workgroup per CU, as k_msd_part_text runs (its LDS allows no second); best of five.
+static int floor_mode(uint64_t records, uint32_t NB, uint32_t r)
+{
+    Rec* out; uint32_t* cursor; uint32_t* base; uint32_t* gbar;
+    CK(hipMalloc(&out, (records + (uint64_t)NB * 4096) * sizeof(Rec)));
+    CK(hipMalloc(&cursor, (size_t)8 * NB * 4));
+    CK(hipMalloc(&base, (size_t)NB * 4));
+    CK(hipMalloc(&gbar, 8 * 64 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    const uint32_t grid = (uint32_t)(cus / 8 * 8);
+    const uint32_t tiles = (uint32_t)(records / ((uint64_t)NB * r));
+    std::vector<uint32_t> hb(NB);
+    for (uint32_t d = 0; d < NB; d++) hb[d] = (uint32_t)((uint64_t)d * tiles * r);
+    CK(hipMemcpy(base, hb.data(), (size_t)NB * 4, hipMemcpyHostToDevice));
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; rep++) {
+        std::vector<uint32_t> hc((size_t)8 * NB, 0u);
+        const uint32_t per_group = (tiles + 7) / 8 * r;
+        for (uint32_t g = 0; g < 8; g++) for (uint32_t d = 0; d < NB; d++) hc[(size_t)g * NB + d] = g * per_group;
+        CK(hipMemcpy(cursor, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(gbar, 0, 8 * 64 * 4));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_scatter_lockstep, dim3(grid), dim3(1024), (size_t)NB * 4, 0, out, base, cursor, NB, r, tiles, gbar, 0u);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+    }
+    printf("{\"store_floor_ms\": %.4f, \"records\": %llu, \"bins\": %u, \"run\": %u, \"grid\": %u, \"bytes\": %llu}\n", best,
+           (unsigned long long)tiles * NB * r, NB, r, grid, (unsigned long long)tiles * NB * r * 12ull);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 4 && !strcmp(argv[1], "--floor"))
+        return floor_mode(strtoull(argv[2], nullptr, 10), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]));
     const uint64_t records = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1500000000ull;
     const uint32_t NB = argc > 2 ? (uint32_t)atoi(argv[2]) : 2700u;
     Rec* out; uint32_t* cursor; uint32_t* base;

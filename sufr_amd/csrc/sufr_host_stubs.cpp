@@ -66,6 +66,7 @@ int sufr_hip_is_wide_(const sufr_hip_ctx*, uint64_t) { return 0; }
 int sufr_hip_ctx_device_(const sufr_hip_ctx*) { return -1; }
 uint64_t sufr_hip_array_budget_(const sufr_hip_ctx*) { return 0; }
 void sufr_hip_release_build_arrays_(sufr_hip_ctx*, int) {}
+void sufr_hip_release_wide_arrays_(sufr_hip_ctx*) {}
 int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t*, uint64_t, uint32_t, uint64_t, const char*, uint32_t, uint32_t,
                              uint64_t*, sufr_hip_stats*, int*, const void**, const void**, const void**) { return no_device(ctx); }
 int sufr_hip_resident_ends_(sufr_hip_ctx* ctx, uint64_t, uint64_t*, uint64_t*) { return no_device(ctx); }

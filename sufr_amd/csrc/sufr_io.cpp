@@ -291,6 +291,7 @@ extern "C" int sufr_hip_build_resident_(sufr_hip_ctx* ctx, const uint8_t* text, 
                                         int* device, const void** d_text, const void** d_sa,
                                         const void** d_lcp);                               // sufr_capi.inc
 extern "C" void sufr_hip_release_build_arrays_(sufr_hip_ctx* ctx, int also_text);
+extern "C" void sufr_hip_release_wide_arrays_(sufr_hip_ctx* ctx);
 extern "C" int sufr_hip_resident_ends_(sufr_hip_ctx* ctx, uint64_t s, uint64_t* first, uint64_t* last);
 extern "C" int sufr_hip_resident_stitch_(sufr_hip_ctx* ctx, uint64_t n, uint64_t prev_last, uint64_t* lcp_out);
 extern "C" int sufr_hip_resident_arrays_(sufr_hip_ctx* ctx, int* device, const void** d_text, const void** d_sa,
@@ -789,6 +790,9 @@ static int wide_shard_build(sufr_hip_ctx* ctx, const sufr_sequence_data* sd, con
         cap = w.s;                                   // (the call reports what it needed)
     }
     if (rc) { wide_free(w); return rc; }
+    // the raw text is not read again: the stitch and the merge use the context's normalised copy, the file's text section comes
+    // from the host (advisor r5: n bytes of HBM held until sufr_hip_shard_write for nothing)
+    (void)hipFree(w.d_text); w.d_text = nullptr;
     info->num_suffixes = w.s;
     if (w.s) {
         uint64_t f = 0, l = 0;
@@ -1138,6 +1142,9 @@ static int create_wide_auto(sufr_hip_ctx* const* ctxs, int n_ctx, uint32_t K0, c
         if (say) fprintf(stderr, "[sufr_hip] windowed create: %u shard%s over %d context%s (array budget %llu): rc %d in %.2f s\n", K, K == 1 ? "" : "s", n_ctx,
                          n_ctx == 1 ? "" : "s", (unsigned long long)budget, rc, now_s() - t0);
         if (rc != SUFR_HIP_E_NOMEM || K >= 64u * (uint32_t)n_ctx) return rc;
+        // the failed attempt's window arrays are sized for K shards and never shrink by themselves: handed back, so that the
+        // retry has what a fresh build with 2 K shards would have (advisor r5)
+        for (int c = 0; c < n_ctx; c++) sufr_hip_release_wide_arrays_(ctxs[c]);
         K *= 2;
     }
 }

@@ -1598,7 +1598,10 @@ __device__ __forceinline__ uint64_t walk_lcp_packed(const uint8_t* __restrict__ 
         const uint32_t sa = (uint32_t)(oa & 7u), sb = (uint32_t)(ob & 7u);
         // two words of K codes, then what the 24 bytes still hold behind them: 192 - 7 - 2 K bits >= K3 whole codes (round 5: the
         // third piece was read and not looked at; 42 -> 61 symbols per round trip for 3-bit codes)
-        const uint32_t K3 = div_by_bits(192u - 7u - 2u * K * (uint32_t)bits, bits);
+        // (K3 <= K: for 5-bit codes the division gives 13 > K = 12 -- a negative shift below; the packed path stops at 4 bits
+        // today, sufr_launch.inc, but the walk must not depend on that: advisor r5)
+        const uint32_t K3raw = div_by_bits(192u - 7u - 2u * K * (uint32_t)bits, bits);
+        const uint32_t K3 = K3raw < K ? K3raw : K;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const uint32_t qa = sa + (uint32_t)j * K * (uint32_t)bits, qb = sb + (uint32_t)j * K * (uint32_t)bits;   // < 8 + 128

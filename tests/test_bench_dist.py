@@ -46,6 +46,31 @@ def test_gpus_n_without_enough_devices_says_how_to_rehearse():
     assert "--share-device" in r.stderr and "SUFR_BENCH_FORCE_DIST" in r.stderr
 
 
+def test_share_device_with_rccl_is_refused_before_anything_starts():
+    """N RCCL ranks on one device die with a duplicate-GPU error in every rank (advisor r5): the parent says what to add and
+    exits 2 (decided before anything touches a GPU: runs in the CPU container too)."""
+    r = _run(["--gpus", "2", "--share-device", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2 and "--backend gloo" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_end_to_end():
+    """BASELINE config C5 at its real shape, rehearsed on the one GPU: `python bench.py --gpus 8 --backend gloo
+    --share-device` -- eight ranks, eight first-digit shards, the eight-writer `sufr create` into ONE file -- at C. elegans size.
+    Eight per-rank records whose shards add up to the N = 1 count; the file is sha256-equal to the single-GPU file."""
+    common = ["--workload", "elegans", "--steps", "2", "--warmup", "1", "--placement-trials", "1", "--e2e-hash"]
+    eight = _line(_run(["--gpus", "8", "--backend", "gloo", "--share-device"] + common, timeout=1500))
+    one = _line(_run(["--gpus", "1", "--no-cpu-baseline", "--no-search"] + common))
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    pr = eight["per_rank"]
+    assert len(pr["device_ms"]) == 8 and sum(r["num_suffixes"] for r in pr["device_ms"]) == one["config"]["num_suffixes"]
+    assert min(r["num_suffixes"] for r in pr["device_ms"]) > 0
+    e8, e1 = eight["e2e_create"], one["e2e_create"]
+    assert "error" not in e8 and "error" not in e1, (e8, e1)
+    assert len(e8["shard_suffixes"]) == 8 and sum(e8["shard_suffixes"]) == one["config"]["num_suffixes"]
+    assert e8["sufr_sha256"] == e1["sufr_sha256"] and len(e8["sufr_sha256"]) == 64
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["ecoli", "elegans"])
 def test_bench_two_ranks_end_to_end(workload):

@@ -133,23 +133,34 @@ def test_many_exception_bytes_fall_back_to_the_general_table(oracle):
     assert exc == 0
 
 
-def test_sharded_builds_with_exception_bytes_concatenate(oracle):
-    """a sharded build takes the general table (the first digit of a re-placed suffix decides its shard): the shards still
-    concatenate to the oracle's arrays"""
-    rng = np.random.default_rng(4)
+@pytest.mark.parametrize("amb", [False, True])
+@pytest.mark.parametrize("shards", [2, 3, 7])
+def test_sharded_builds_with_exception_bytes_concatenate(oracle, shards, amb):
+    """shards are first-digit ranges of the text as it was BUILT ('N' for the listed bytes); a suffix with a listed byte among
+    its first five characters may truly belong to another shard: every rank takes all such suffixes out, keeps the ones whose
+    true first bytes lie in its range and adds the other shards' that do -- the shards concatenate to the oracle's arrays,
+    every suffix in exactly one of them.  Letters below 'A', between the table's letters and above 'T', clustered at the
+    start of many suffixes."""
+    rng = np.random.default_rng(4 + shards)
     raw = _acgt(rng, 400_000)
-    raw[rng.integers(0, raw.size - 1, 30)] = IUPAC[rng.integers(0, 10, 30)]
+    raw[rng.integers(0, raw.size - 1, 60)] = np.frombuffer(b"RYKMSWBDHV*#Z!", dtype=np.uint8)[rng.integers(0, 14, 60)]
+    raw[1000:1004] = np.frombuffer(b"RYRY", dtype=np.uint8)
+    raw[-3] = ord("W")
     raw[-1] = ord("$")
     x = torch.from_numpy(raw).cuda()
     db = sufr_amd.DeviceBuilder(0)
     parts_sa, parts_lcp = [], []
-    for k in range(3):
-        sa, lcp = db.sort(x, raw_text=True, is_dna=True, shard_index=k, num_shards=3)
+    for k in range(shards):
+        sa, lcp = db.sort(x, raw_text=True, is_dna=True, allow_ambiguity=amb, shard_index=k, num_shards=shards)
+        assert db.stats.num_exceptions > 0 and db.stats.bits_per_char == 3
+        assert db.stats.num_suffixes == sa.numel()
         parts_sa.append(sa.cpu().numpy().view(np.uint32).copy()); parts_lcp.append(lcp.cpu().numpy().view(np.uint32).copy())
     db.close()
-    osa, olcp, _ = oracle.build(raw, is_dna=True, threads=8)
+    osa, olcp, _ = oracle.build(raw, is_dna=True, allow_ambiguity=amb, threads=8)
     gsa = np.concatenate(parts_sa); glcp = np.concatenate(parts_lcp)
-    assert np.array_equal(gsa, osa)
+    assert gsa.size == osa.size
+    bad = np.nonzero(gsa != osa)[0]
+    assert bad.size == 0, f"SA differs at rank {bad[0]}: got {gsa[bad[0]]} want {osa[bad[0]]} ({bad.size} ranks; shard sizes {[p.size for p in parts_sa]})"
     starts = np.cumsum([0] + [p.size for p in parts_sa[:-1]])
     keep = np.ones(osa.size, dtype=bool); keep[starts[1:]] = False      # (a shard's first LCP is the stitch's)
     assert np.array_equal(glcp[keep], olcp[keep])
