@@ -131,7 +131,10 @@ def cpu_baseline(text_cpu: np.ndarray, flags: dict, partitions: int, target_s: f
     sweep_note = (f"first {nb} bases of the same text (+'$'), {s} suffixes, {partitions} partitions; best of the sweep: "
                   f"{bt} threads, {dt:.2f} s wall (partition {st.t_partition:.2f} s, sort {st.t_sort:.2f} s)")
     out = {"value": rate, "unit": "suffixes/s", "cores": bt, "best_threads": bt, "host_cores": cores, "kind": "port",
-           "threads_sweep": sweep, "sample": sweep_note, "sample_only": True}
+           "threads_sweep": sweep, "sample": sweep_note, "sample_only": True,
+           "caveat": (f"a C port of the reference algorithm (oracle/), not the reference: its OpenMP partition + merge-sort loops peak at "
+                      f"{bt} of this host's {cores} hardware threads and get slower beyond (threads_sweep); the reference's Rust / rayon "
+                      "loops may use the cores better.  A stated baseline, not a target: no claim rests on the GPU / CPU ratio")}
     if full_text is not None:
         try:
             whole = full_text()
