@@ -13,18 +13,23 @@ from sufr_amd import synth
 from oracle_helper import Oracle
 
 bases = int(sys.argv[1]) if len(sys.argv) > 1 else 3_100_000_000
-mode = sys.argv[2] if len(sys.argv) > 2 else "ignore_softmask"       # or "dna": the soft-masked repeats indexed (Makefile:79)
-soft = mode == "ignore_softmask"
+mode = sys.argv[2] if len(sys.argv) > 2 else "ignore_softmask"       # or "dna": the soft-masked repeats indexed (Makefile:79);
+soft = mode in ("ignore_softmask", "iupac")                          # "iupac": the headline flags on the text with 50 IUPAC letters planted
 mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2**30
 need_gb = bases * (24 if soft else 48) / 2**30
 print(f"host memory {mem_gb:.0f} GB, this run needs ~{need_gb:.0f} GB", flush=True)
 if mem_gb < need_gb * 1.5:
     sys.exit("not enough host memory for the oracle at this size")
 x, _ = synth.syn_human(bases, seed=4, device="cuda")
+if mode == "iupac":          # (round 6: bytes outside {$ % A C G N T} keep the 3-bit table, sufr_exc.inc)
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    at = torch.randint(1000, x.numel() - 1000, (50,), generator=g, device="cuda")
+    x[at] = torch.tensor(list(b"RYKMSWBDHV" * 5), dtype=torch.uint8, device="cuda")
 db = sufr_amd.DeviceBuilder(0)
 sa, lcp = db.sort(x, is_dna=True, ignore_softmask=soft, raw_text=True, num_partitions=256)
 st = db.stats
-print(f"GPU build: n={x.numel()} s={st.num_suffixes} device {st.ms_total:.1f} ms, {st.num_levels} levels", flush=True)
+print(f"GPU build ({mode}): n={x.numel()} s={st.num_suffixes} device {st.ms_total:.1f} ms, {st.num_levels} levels, "
+      f"{st.num_exceptions} bytes outside the DNA table, {st.num_reinserted} suffixes re-placed", flush=True)
 gsa = sa.cpu().numpy().view(np.uint32); glcp = lcp.cpu().numpy().view(np.uint32)
 raw = x.cpu().numpy()
 del x, sa, lcp
