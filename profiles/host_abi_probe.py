@@ -34,6 +34,11 @@ for rep in range(reps):
                               n, C.byref(ns), C.byref(st))
     dt = time.perf_counter() - t0
     ctx.check(rc)
+    if rep == 0:        # the text that came back under the build is the reference's text map of the input (lowercase -> 'N')
+        want = np.where((raw >= 97) & (raw <= 122), np.uint8(78), raw)
+        assert np.array_equal(norm, want), "normalised text differs"
+        assert int(sa[:ns.value].astype(np.uint64).sum()) > 0 and int(lcp[0]) == 0
+        del want
     gb = (2 * n + 8 * ns.value) / 1e9
     print(f"call {rep}: {dt:.3f} s  ({gb:.1f} GB over PCIe: {gb / dt:.1f} GB/s)  H2D {st.host_read_s:.3f} s, build {st.host_build_s:.3f} s "
           f"(device {st.ms_total:.1f} ms), D2H {st.host_write_s:.3f} s  suffixes={ns.value}", flush=True)
