@@ -720,8 +720,8 @@ def main():
                                "note": "strong scaling with a per-rank fixed cost: every rank reads the whole text in the text "
                                        "pass (text_pass_ms) and in the scan of the partition kernel (~2.5 ms of ms_partition at "
                                        "3.1 Gb); sorting work (ms_passes, ms_deep, the rest of ms_partition) is ~1/N.  One-GPU "
-                                       "shard probe (profiles/r06_shard_probe.txt): 51.9 / 29.2 / 19.7 / 14.3 ms per rank at "
-                                       "N = 1 / 2 / 4 / 8 => at most 89 / 66 / 45 % efficiency before any communication"}
+                                       "shard probe (profiles/r06_shard_probe.txt): 51.0 / 29.3 / 19.7 / 14.1 ms per rank at "
+                                       "N = 1 / 2 / 4 / 8 => at most 87 / 65 / 45 % efficiency before any communication"}
             if args.share_device:
                 out["per_rank"]["share_device"] = ("all ranks ran on cuda:0 (smoke test of the N > 1 leg on a one-GPU box): "
                                                    "value is NOT an N-GPU figure")

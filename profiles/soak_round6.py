@@ -1,8 +1,8 @@
 """A soak of round 6's two new paths against the CPU checker with fresh seeds:   python profiles/soak_round6.py [minutes] [seed]
 (1) DNA texts with random bytes outside {$ % A C G N T} planted (IUPAC letters, '#', bytes below '$' and above 'T'; single bytes,
 clusters, runs, inside N runs and repeats), random flags, 1-5 shards: the shards concatenated = the oracle's arrays.
-(2) --max-query-len L for random L in 11..21 (the capped build built directly), 1-4 shards: = the canonical form computed from
-the oracle's exact arrays.  Prints one line per failure and a summary; exit code 1 when anything differed.
+(2) --max-query-len L for random L in 11..21 (the capped build built directly), half of them with such bytes planted too, 1-4
+shards: = the canonical form computed from the oracle's exact arrays.  Prints one line per failure and a summary; exit code 1 when anything differed.
 (Test-side tooling: it imports the checker from tests/, like the tests do.)"""
 import os
 import sys
@@ -107,6 +107,8 @@ while time.time() < t_end:
                   f"({gsa.size} vs {osa.size} suffixes)", flush=True)
     else:
         L = int(rng.integers(11, 22)); shards = int(rng.choice([1, 1, 2, 4]))
+        if rng.random() < 0.5:                                 # capped builds with listed bytes: re-placed under the capped order
+            raw = plant(rng, raw); raw[-1] = ord("$")
         x = torch.from_numpy(raw).cuda()
         norm = oracle.normalize(raw, soft)
         try:

@@ -119,3 +119,40 @@ def test_caps_outside_the_key_keep_the_two_step_form(oracle):
     for L in (3, 10, 22, 60):
         st = _check(oracle, raw, L)
         assert st.chars_per_key == 21
+
+
+@pytest.mark.parametrize("L,shards", [(11, 1), (12, 1), (16, 3), (21, 2)])
+@pytest.mark.parametrize("amb", [False, True])
+def test_capped_builds_with_bytes_outside_the_dna_table(oracle, L, shards, amb):
+    """a real assembly's IUPAC letters must not take a `-m` build off the direct path either: the build runs on 'N' for the listed
+    bytes, and the suffixes whose first L symbols hold one are re-placed under the CAPPED order (first L true bytes, ties in
+    descending position).  Letters inside copies of a repeat (equal L-prefixes with and without the letter), next to each other,
+    in a homopolymer run; one shard and several."""
+    rng = np.random.default_rng(100 * L + shards + amb)
+    raw = _acgt(rng, 700_000, p=[0.4, 0.2, 0.2, 0.2])
+    seg = _acgt(rng, 300)
+    for i, c in enumerate(b"RNTAYRK-"):
+        s_ = seg.copy(); s_[150] = c
+        raw[50_000 + i * 70_000:50_000 + i * 70_000 + 300] = s_
+    raw[600_000:640_000] = ord("A"); raw[620_000] = ord("W"); raw[620_001] = ord("S")
+    raw[rng.integers(0, raw.size - 1, 40)] = np.frombuffer(b"RYKMSWBDHV#", dtype=np.uint8)[rng.integers(0, 11, 40)]
+    raw[-1] = ord("$")
+    osa, olcp, _ = oracle.build(raw, is_dna=True, allow_ambiguity=amb, threads=8)
+    wsa, wlcp = canonical(osa, olcp, L)
+    x = torch.from_numpy(raw).cuda()
+    db = sufr_amd.DeviceBuilder(0)
+    sas, lcps = [], []
+    for k in range(shards):
+        sa, lcp = db.sort(x, raw_text=True, is_dna=True, allow_ambiguity=amb, max_query_len=L, shard_index=k, num_shards=shards)
+        assert db.stats.num_exceptions > 0 and db.stats.chars_per_key == L and db.stats.bits_per_char == 3
+        sas.append(sa.cpu().numpy().view(np.uint32).copy()); lcps.append(lcp.cpu().numpy().view(np.uint32).copy())
+    db.close()
+    gsa = np.concatenate(sas); glcp = np.concatenate(lcps)
+    assert gsa.size == wsa.size
+    bad = np.nonzero(gsa != wsa)[0]
+    assert bad.size == 0, f"SA differs at rank {bad[0]}: got {gsa[bad[0]]} want {wsa[bad[0]]} ({bad.size} ranks)"
+    starts = np.cumsum([0] + [p.size for p in sas[:-1]])
+    keep = np.ones(wsa.size, dtype=bool); keep[starts[1:]] = False
+    bad = np.nonzero((glcp != wlcp) & keep)[0]
+    assert bad.size == 0, f"LCP differs at rank {bad[0]}: got {glcp[bad[0]]} want {wlcp[bad[0]]} ({bad.size} ranks)"
+
