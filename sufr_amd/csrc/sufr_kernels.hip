@@ -217,6 +217,21 @@ k_zero_ranges(uint8_t* __restrict__ p0, uint8_t* __restrict__ p1, uint8_t* __res
     if (z.bytes[7]) zero_range(p7, z.bytes[7], tid, nth);
 }
 
+// Small results for the host, published by the device itself: the queued (source, size) pairs are copied into MAPPED pinned
+// memory and a sequence number is stored behind them; the host spins on that word instead of paying for a copy command and a
+// stream synchronisation (7 against 16 us per round trip, profiles/micro/readback.hip; Pipeline::sync_reads).
+struct PubList { const uint32_t* src[8]; uint32_t words[8]; uint32_t off[8]; uint32_t n; };
+__global__ void __launch_bounds__(256)
+k_publish(PubList pl, uint32_t* __restrict__ host, unsigned long long* __restrict__ flag, unsigned long long seq)
+{
+    for (uint32_t r = 0; r < pl.n; r++)
+        for (uint32_t i = threadIdx.x; i < pl.words[r]; i += 256)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(pl.src[r] + i), host + pl.off[r] + i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_text_pass_dna: THE one pass over the raw text of a DNA build (replaces the text map of SufrBuilder::new,
 // sufr_builder.rs:144-160, and everything the pivot selection 771-809 needed to know about the text).
